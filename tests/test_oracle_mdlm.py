@@ -1,0 +1,100 @@
+"""CPU: the oracle restatement vs goldens captured from the reference import
+(tools/refgen/make_goldens.py).  fp32 vs fp32 on the same CPU -> tight tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import cls_guidance as ocg
+from oracle import dit as odit
+from oracle import mdlm as omdlm
+from oracle import mlp as omlp
+from sgpo_amd import weights as W
+
+DIM_KEYS = ('hidden', 'cond_dim', 'n_blocks', 'n_heads')
+
+
+def _sd(g):
+    dims = dict(zip(DIM_KEYS, [int(v) for v in g['dims']]))
+    return W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
+
+
+@pytest.mark.parametrize('name', ['dit_small_s0', 'dit_small_s1', 'dit_real_s0', 'dit_real_s1'])
+def test_dit_forward(name):
+    g = load_golden(name)
+    sd = _sd(g)
+    logits, hs = odit.dit_forward(sd, g['x'], g['sigma'], return_hidden_states=True)
+    torch.testing.assert_close(hs[1], g['h1'], rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(hs[-1], g['h_last'], rtol=1e-4, atol=2e-5)
+    torch.testing.assert_close(logits, g['logits'], rtol=1e-4, atol=2e-5)
+    l2 = odit.dit_forward(sd, g['x'], g['sigma'], x_emb=g['h_last'] * 0.5 + 0.1)
+    torch.testing.assert_close(l2, g['logits_xemb'], rtol=1e-4, atol=2e-5)
+
+
+def test_mdlm_p_sample_and_q_sample():
+    g = load_golden('mdlm_small')
+    sd = _sd(g)
+    T = int(g['T'])
+    x = g['x']
+    logp = omdlm.forward(sd, x, torch.zeros(x.shape[0]), 28)
+    torch.testing.assert_close(logp, g['logp'], rtol=1e-4, atol=1e-4)
+    for t in (127, 64, 1):
+        q = omdlm.p_sample(sd, x, t, T, 28, hard=False)
+        torch.testing.assert_close(q, g[f'soft_t{t}'], rtol=1e-4, atol=1e-7)
+        xh = omdlm.p_sample(sd, x, t, T, 28, hard=True, u=g[f'u_t{t}'])
+        assert torch.equal(xh, g[f'hard_t{t}'])
+    # defect D2: mask column equals (1-eps) t / T^2
+    q = omdlm.p_sample(sd, x, 127, T, 28, hard=False)
+    assert abs(float(q[0, 0, 28]) - 0.999 * 127 / 128 / 128) < 1e-7
+    xq = omdlm.q_sample(g['x_clean'], g['tq'], T, 28, g['uq'])
+    assert torch.equal(xq, g['q_sample'])
+    assert abs(float(omdlm.total_noise(torch.tensor(64 / T))) - float(g['sigma_64'])) < 1e-7
+
+
+def test_udlm_p_sample():
+    g = load_golden('udlm_small')
+    sd = _sd(g)
+    T = int(g['T'])
+    for t in (127, 3):
+        kw = dict(diffusion='uniform', parameterization='d3pm', time_conditioning=True)
+        q = omdlm.p_sample(sd, g['x'], t, T, 28, hard=False, **kw)
+        torch.testing.assert_close(q, g[f'soft_t{t}'], rtol=2e-4, atol=1e-7)
+        xh = omdlm.p_sample(sd, g['x'], t, T, 28, hard=True, u=g[f'u_t{t}'], **kw)
+        assert torch.equal(xh, g[f'hard_t{t}'])
+
+
+def test_mdlm_sample():
+    g = load_golden('mdlm_sample_small')
+    sd = _sd(g)
+    x = omdlm.sample(sd, g['x'].shape[0], g['x'].shape[1], int(g['T']), 28, g['us'])
+    assert torch.equal(x, g['x'])
+
+
+def test_mlp():
+    g = load_golden('mlp_creilov')
+    sd = W.mlp_synthetic_state(seed=int(g['seed']), n_residues=119)
+    y = omlp.mlp_forward(sd, g['x'], g['t'])
+    torch.testing.assert_close(y, g['y'], rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(omlp.Predictor(sd).log_likelihood(g['x']), g['ll'], rtol=1e-5, atol=1e-6)
+    g = load_golden('mlp_trpb')
+    sd = W.mlp_synthetic_state(seed=int(g['seed']), n_residues=15)
+    res = [int(r) for r in g['residues']]
+    y = omlp.mlp_forward(sd, g['x'], g['t'], residues=res)
+    torch.testing.assert_close(y, g['y'], rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize('tag', ['unguided', 'guided'])
+def test_cls_guidance_inference(tag):
+    g = load_golden(f'cg_small_{tag}')
+    sd = _sd(g)
+    temp = float(g['temp'])
+    B, L = g['x'].shape
+    msd = W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=L)
+    pred = omlp.Predictor(msd)
+    # per-step guided rates at a fixed state
+    q = omdlm.p_sample(sd, g['xs'], 9, int(g['T']), 28, hard=False)
+    torch.testing.assert_close(q, g['q'], rtol=1e-4, atol=1e-7)
+    qg, _ = omdlm.get_guided_rates(pred, g['xs'], 9, q.clone(), 31, guide_temp=temp)
+    torch.testing.assert_close(qg, g['qg'], rtol=2e-4, atol=1e-7)
+    x = ocg.inference_mdlm(sd, B, L, int(g['T']), 28, g['es'], predictor=pred, temperature=temp)
+    assert torch.equal(x, g['x'])

@@ -1,0 +1,238 @@
+"""Generate tests/golden/*.npz by importing the reference (/root/reference) on
+CPU with the stand-ins of tools/refgen/standins.py (SURVEY.md §8c recipe).
+
+Runs in the build container only.  The goldens hold inputs, injected noise and
+the REFERENCE's outputs; weights are regenerated at test time from the seeded
+initialisers of sgpo_amd/weights.py (the seed and dims are stored in each file).
+
+    python tools/refgen/make_goldens.py [--only mdlm,mlp,...]
+"""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.abspath(os.path.join(HERE, '..', '..'))
+REF = '/root/reference'
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+
+import standins  # noqa: E402
+
+standins.install()
+sys.path.insert(0, REF)
+
+from sgpo_amd import weights as W  # noqa: E402
+
+OUT = os.path.join(ROOT, 'tests', 'golden')
+CREILOV = ('MAGLRHTFVVADATLPDCPLVYASEGFYAMTGYGPDEVLGHNARFLQGEGTDPKEVQKIRDAIKKGEACSVRLLNYRKDGTPFWNLL'
+           'TVTPIKTPDGRVSKFVGVQVDVTSKTEGKALA')
+TRPB_RES = [117, 118, 119, 162, 166, 182, 183, 184, 185, 186, 227, 228, 230, 231, 301]
+
+
+def save(name, **arrs):
+    out = {}
+    for k, v in arrs.items():
+        if torch.is_tensor(v):
+            v = v.detach().cpu().numpy()
+        out[k] = np.asarray(v)
+    path = os.path.join(OUT, name + '.npz')
+    np.savez_compressed(path, **out)
+    print(f'{name}: {os.path.getsize(path) / 1024:.1f} KiB')
+
+
+# ----------------------------------------------------------------------------
+def dit_config(hidden=512, cond_dim=128, n_blocks=8, n_heads=8, diffusion='absorbing_state',
+               parameterization='subs', time_conditioning=False):
+    return standins.to_attr(dict(
+        diffusion=diffusion, backbone='dit', parameterization=parameterization,
+        time_conditioning=time_conditioning, T=0, subs_masking=False,
+        training=dict(ema=0, antithetic_sampling=True, importance_sampling=False,
+                      sampling_eps=1e-3, change_of_variables=False),
+        optim=dict(lr=3e-4), sampling=dict(predictor='ddpm', steps=128, noise_removal=True),
+        model=dict(hidden_size=hidden, cond_dim=cond_dim, length=1024, n_blocks=n_blocks,
+                   n_heads=n_heads, scale_by_sigma=True, dropout=0.1),
+        noise=dict(type='loglinear'), eval_batch_size=2))
+
+
+def build_ref_mdlm(dims, seed, L, T=128, **cfgkw):
+    """Reference MDLM wrapper object with synthetic weights (bypasses checkpoint loading)."""
+    from models.pretraining.model.mdlm_diffusion import MDLMDiffusion, _sample_categorical
+    import models.mdlm as ref_mdlm
+    ref_mdlm._sample_categorical = _sample_categorical  # defect D1
+    cfg = dit_config(hidden=dims['hidden'], cond_dim=dims['cond_dim'], n_blocks=dims['n_blocks'],
+                     n_heads=dims['n_heads'], **cfgkw)
+    core = MDLMDiffusion(cfg, tokenizer={'_target_': 'evodiff.utils.Tokenizer'})
+    sd = W.dit_synthetic_state(seed=seed, vocab=31, hidden=dims['hidden'], cond_dim=dims['cond_dim'],
+                               n_blocks=dims['n_blocks'], n_heads=dims['n_heads'])
+    missing = core.backbone.load_state_dict(sd, strict=True)
+    core.eval()
+    core.set_length = lambda n: None
+    net = object.__new__(ref_mdlm.MDLM)
+    net.tokenizer = core.tokenizer
+    net.model = core
+    net.S = core.vocab_size
+    net.timestep = T
+    net.length = L
+    net.device = 'cpu'
+    net.diffusion = cfg.diffusion
+    net.parameterization = cfg.parameterization
+    return net, core, sd
+
+
+SMALL = dict(hidden=128, cond_dim=32, n_blocks=2, n_heads=2)
+REAL = dict(hidden=512, cond_dim=128, n_blocks=8, n_heads=8)
+
+
+def gen_dit():
+    for tag, dims, B, L in (('small', SMALL, 3, 37), ('real', REAL, 2, 119)):
+        net, core, sd = build_ref_mdlm(dims, seed=11, L=L)
+        g = torch.Generator().manual_seed(5)
+        x = torch.randint(0, 31, (B, L), generator=g)
+        x[:, ::3] = 28
+        for sname, sigma in (('s0', torch.zeros(B)), ('s1', torch.tensor([0.3, 1.7, 4.0][:B]))):
+            with torch.no_grad():
+                logits, hs = core.backbone(x, sigma, return_hidden_states=True)
+                logits2 = core.backbone(x, sigma, x_emb=hs[-1] * 0.5 + 0.1)
+            save(f'dit_{tag}_{sname}', seed=11, dims=np.array(list(dims.values())), x=x, sigma=sigma,
+                 logits=logits, h_last=hs[-1], h1=hs[1], logits_xemb=logits2)
+
+
+def gen_mdlm():
+    B, L, T = 3, 37, 128
+    net, core, sd = build_ref_mdlm(SMALL, seed=12, L=L, T=T)
+    g = torch.Generator().manual_seed(6)
+    x = torch.randint(0, 26, (B, L), generator=g)
+    x[:, ::2] = 28
+    out = dict(seed=12, dims=np.array(list(SMALL.values())), x=x, T=T)
+    with torch.no_grad():
+        for t in (127, 64, 1):
+            out[f'soft_t{t}'] = net.p_sample(x, torch.tensor(t), hard=False)
+            torch.manual_seed(100 + t)
+            u = torch.rand(B, L, 31)
+            torch.manual_seed(100 + t)
+            out[f'hard_t{t}'] = net.p_sample(x, torch.tensor(t), hard=True)
+            out[f'u_t{t}'] = u
+        out['logp'] = core.forward(x, torch.zeros(B))
+        # q_sample
+        tq = torch.tensor([5, 64, 127])
+        torch.manual_seed(7)
+        uq = torch.rand(B, L)
+        torch.manual_seed(7)
+        out['q_sample'] = net.q_sample(x.clone().clamp(max=25), tq)
+        out['tq'] = tq
+        out['uq'] = uq
+        out['x_clean'] = x.clone().clamp(max=25)
+        out['sigma_64'] = net.sigma(torch.tensor(64))
+    save('mdlm_small', **out)
+
+    # UDLM (uniform diffusion, d3pm parameterization, time conditioned)
+    net, core, sd = build_ref_mdlm(SMALL, seed=13, L=L, T=T, diffusion='uniform',
+                                   parameterization='d3pm', time_conditioning=True)
+    x = torch.randint(0, 31, (B, L), generator=g)
+    out = dict(seed=13, dims=np.array(list(SMALL.values())), x=x, T=T)
+    with torch.no_grad():
+        for t in (127, 3):
+            out[f'soft_t{t}'] = net.p_sample(x, torch.tensor(t), hard=False)
+            torch.manual_seed(200 + t)
+            u = torch.rand(B, L, 31)
+            torch.manual_seed(200 + t)
+            out[f'hard_t{t}'] = net.p_sample(x, torch.tensor(t), hard=True)
+            out[f'u_t{t}'] = u
+    save('udlm_small', **out)
+
+    # MDLM.sample (Uncond path): _sample with ddpm predictor, 6 steps
+    net, core, sd = build_ref_mdlm(SMALL, seed=14, L=L, T=6)
+    core.length = L
+    core.config.eval_batch_size = B
+    torch.manual_seed(9)
+    us = [torch.rand(B, L, 31) for _ in range(6)]
+    torch.manual_seed(9)
+    with torch.no_grad():
+        xs = net.sample(B)
+    save('mdlm_sample_small', seed=14, dims=np.array(list(SMALL.values())), us=torch.stack(us), x=xs, T=6)
+
+
+def data_cfg(name):
+    if name == 'CreiLOV':
+        return standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=119,
+                                     full_seq=CREILOV, residues=None))
+    raise KeyError(name)
+
+
+def build_ref_mlp(n_res_cfg, residues, seed, full_len):
+    import problem.protein as ref_pp
+    dc = standins.to_attr(dict(alphabet_size=31, residues=residues, full_seq='A' * full_len))
+    mc = standins.to_attr(dict(hidden_dim=64))
+    m = ref_pp.MLPModel(dc, mc)
+    sd = W.mlp_synthetic_state(seed=seed, n_residues=n_res_cfg)
+    m.load_state_dict(sd, strict=True)
+    m.eval()
+    pred = object.__new__(ref_pp.ProteinPredictor)
+    torch.nn.Module.__init__(pred)
+    pred.device = 'cpu'
+    pred.model = m
+    return pred, sd
+
+
+def gen_mlp():
+    g = torch.Generator().manual_seed(21)
+    # CreiLOV-like: residues None, D = 119
+    pred, sd = build_ref_mlp(119, None, seed=31, full_len=119)
+    x = torch.randint(0, 31, (5, 119), generator=g)
+    t = torch.tensor([0., 1., 17., 64., 127.])
+    with torch.no_grad():
+        y = pred(x, t)
+        ll = pred.log_likelihood(x)
+    save('mlp_creilov', seed=31, x=x, t=t, y=y, ll=ll)
+    # TrpB-like: 15 residues, 1-indexed list used raw (defect D3)
+    pred, sd = build_ref_mlp(15, TRPB_RES, seed=32, full_len=389)
+    x = torch.randint(0, 26, (5, 389), generator=g)
+    with torch.no_grad():
+        y = pred(x, t)
+        ll = pred.log_likelihood(x)
+    save('mlp_trpb', seed=32, x=x, t=t, y=y, ll=ll, residues=np.array(TRPB_RES))
+
+
+def gen_cg():
+    """Full Classifier_Guidance_Inpaint.inference on a small MDLM, guided + unguided."""
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, T = 2, 24, 16
+    net, core, sd = build_ref_mdlm(SMALL, seed=15, L=L, T=T)
+    full = CREILOV[:L]
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L,
+                               full_seq=full, residues=None))
+    pred, msd = build_ref_mlp(L, None, seed=33, full_len=L)
+    for tag, temp in (('unguided', 0.0), ('guided', 0.5)):
+        algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred, temperature=temp, device='cpu')
+        torch.manual_seed(77)
+        es = [torch.empty(B * L, 31).exponential_(1) for _ in range(T - 1)]
+        torch.manual_seed(77)
+        with torch.no_grad():
+            x = algo.inference(num_samples=B)
+        # per-step guided rates at one fixed state for logits-level parity
+        g = torch.Generator().manual_seed(3)
+        xs = torch.randint(0, 26, (B, L), generator=g)
+        xs[:, ::4] = 28
+        with torch.no_grad():
+            q = net.p_sample(xs, torch.tensor(9), hard=False)
+            qg = net.get_guided_rates(pred, xs, torch.tensor(9), q.clone(), guide_temp=temp)
+        save(f'cg_small_{tag}', seed=15, mlp_seed=33, dims=np.array(list(SMALL.values())), T=T,
+             temp=temp, es=torch.stack(es).view(T - 1, B, L, 31), x=x, xs=xs, q=q, qg=qg,
+             full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
+
+
+GENS = dict(dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg)
+
+if __name__ == '__main__':
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--only', default='')
+    a = ap.parse_args()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(8)
+    names = [n for n in a.only.split(',') if n] or list(GENS)
+    for n in names:
+        GENS[n]()
