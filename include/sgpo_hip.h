@@ -1,0 +1,143 @@
+/* libsgpo_hip.so -- C ABI of the MI355X-native SGPO guided-sampling hot path.
+ *
+ * Every entry point replaces a piece of the reference's PyTorch sampling path
+ * (citations are file:line into the reference repo, ezirayw/SGPO).  The
+ * reference has no FFI of its own: its "plugin API" is the Python duck-type
+ * `GenerativeModel` / `Algo` (models/base.py:4-18, sampling/base.py:5-72).  The
+ * host mirror in sgpo_amd/dropin/ keeps those Python signatures and calls the
+ * functions below through ctypes.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all tensor pointers are DEVICE pointers
+ *     unless a parameter says "host".
+ *   - token tensors are int64 [B][L] row-major (torch.long), logits/probabilities
+ *     fp32 [B][L][K] row-major.
+ *   - the caller owns every buffer (including workspaces); the library owns only
+ *     the opaque model handles created by *_create.
+ *   - calls are asynchronous on `stream` (a hipStream_t passed as void*); no
+ *     internal synchronisation, no allocation outside *_create / sgpo_init.
+ *   - return 0 on success, negative on error; sgpo_last_error() gives the text.
+ *     Nothing throws across the ABI.
+ *   - noise: noise_mode 0 = in-kernel Philox4x32-10 keyed by (seed, call offset,
+ *     GLOBAL element index) so results are invariant to how a batch is sharded
+ *     over ranks (row_offset = first global row of this shard); noise_mode 1/2 =
+ *     the caller passes the noise tensor (parity runs).
+ */
+#ifndef SGPO_HIP_H
+#define SGPO_HIP_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SGPO_NOISE_PHILOX 0
+#define SGPO_NOISE_EXPONENTIAL 1 /* noise = Exp(1) draws e; sample = argmax(p / e)  (torch.multinomial) */
+#define SGPO_NOISE_UNIFORM 2     /* noise = U[0,1) draws u; sample = argmax(p / (1e-10 - log(u + 1e-10))) */
+
+#define SGPO_STEP_SOFT 0    /* write q (unnormalised soft reverse probabilities), no sampling */
+#define SGPO_STEP_SOFT_CG 1 /* classifier-guidance step: reweight, normalise, multinomial */
+#define SGPO_STEP_HARD 2    /* p_sample(hard=True): _sample_categorical + carry-over unmasking */
+
+typedef struct sgpo_dit sgpo_dit;
+typedef struct sgpo_mlp sgpo_mlp;
+typedef struct sgpo_bytenet sgpo_bytenet;
+
+typedef struct {
+  int vocab;      /* 31 */
+  int hidden;     /* 512 */
+  int cond_dim;   /* 128 */
+  int freq_dim;   /* 256 */
+  int n_blocks;   /* 8 */
+  int n_heads;    /* 8 (head_dim must be 64) */
+  int mlp_hidden; /* 2048 */
+  int max_len;    /* RoPE table length (config model.length, 1024) */
+} sgpo_dit_config;
+
+/* ---- library ------------------------------------------------------------ */
+int sgpo_init(int device);            /* binds the calling process to `device`, one rank per GPU */
+const char* sgpo_last_error(void);    /* thread-local message of the last failing call */
+int sgpo_version(void);
+
+/* ---- MDLM denoiser: DIT.forward (dit.py:375-418), blocks dit.py:244-288 ------ */
+/* blob: fp32 parameters (device pointer) concatenated in state_dict order:
+ *   vocab_embed.embedding, sigma_map.mlp.0.{weight,bias}, sigma_map.mlp.2.{weight,bias},
+ *   per block: norm1.weight, attn_qkv.weight, attn_out.weight, norm2.weight,
+ *              mlp.0.{weight,bias}, mlp.2.{weight,bias}, adaLN_modulation.{weight,bias},
+ *   output_layer: norm_final.weight, linear.{weight,bias}, adaLN_modulation.{weight,bias}.
+ * The library keeps its own bf16/fp32 copies; the blob may be freed afterwards. */
+size_t sgpo_dit_param_count(const sgpo_dit_config* cfg);
+int sgpo_dit_create(const sgpo_dit_config* cfg, const float* blob, size_t n_floats, sgpo_dit** out);
+void sgpo_dit_destroy(sgpo_dit* m);
+size_t sgpo_dit_workspace_bytes(const sgpo_dit* m, int B, int L);
+/* tokens [B][L]; sigma [n_sigma] (n_sigma = 1 broadcasts, NULL = sigma 0, i.e.
+ * time_conditioning False, mdlm_diffusion.py:371-372); x_emb (optional, [B][L][hidden] fp32)
+ * bypasses the blocks (dit.py:397-410); hidden_out (optional) receives the last hidden state
+ * (return_hidden_states, dit.py:407-408); logits [B][L][vocab] fp32. */
+int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float* sigma, int n_sigma, int B, int L,
+                     const float* x_emb, float* logits, float* hidden_out, void* workspace,
+                     size_t workspace_bytes, void* stream);
+
+/* ---- fused reverse step, MDLM absorbing state ----------------------------------
+ * Covers MDLMDiffusion._subs_parameterization (mdlm_diffusion.py:325-341),
+ * MDLM.p_sample (models/mdlm.py:55-98), the classifier-guidance reweighting and
+ * torch.multinomial of Classifier_Guidance_Inpaint.inference (sampling/cls_guidance.py:38-52),
+ * the ratio clamp/exp of get_guided_rates (models/mdlm.py:399-409) and
+ * _sample_categorical (mdlm_diffusion.py:69-73).
+ *   log_ratio: [B][n_slots][K] raw log-ratios f(x with x_d<-s) - f(x) (NULL or guide_temp 0 = unguided);
+ *   slot_of_pos: [L] slot index of each position or -1 (NULL = identity, n_slots = L);
+ *   move_chance_t/s: scalars of models/mdlm.py:67-68 (host computes them, incl. defect D2);
+ *   noise: [B][L][K] for noise_mode 1/2;  probs_out (optional) [B][L][K];
+ *   nan_flag (optional): set to 1 if a guided rate is NaN (models/mdlm.py:410-411). */
+int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* log_ratio,
+                           const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
+                           float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
+                           int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                           uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
+                           void* stream);
+
+/* UDLM variant: _d3pm_parameterization + _compute_posterior (mdlm_diffusion.py:343-348, 392-419)
+ * + models/mdlm.py:87-95.  step_mode SOFT or HARD. */
+int sgpo_reverse_step_udlm(const float* logits, const int64_t* x, int B, int L, int K,
+                           float move_chance_t, float move_chance_s, int step_mode, int noise_mode,
+                           const float* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
+                           int64_t* x_out, float* probs_out, void* stream);
+
+/* MDLM.q_sample -> q_xt (models/mdlm.py:104-109, mdlm_diffusion.py:585-597): re-mask each
+ * position w.p. move_chance[b].  noise: [B][L] uniforms for noise_mode 2. */
+int sgpo_q_sample_mdlm(const int64_t* x, const float* move_chance, int B, int L, int mask_index,
+                       int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                       uint64_t row_offset, int64_t* x_out, void* stream);
+
+/* Categorical sampler on its own: rows x K probabilities (need not be normalised). */
+int sgpo_categorical_sample(const float* probs, int64_t rows, int K, int noise_mode, const float* noise,
+                            uint64_t seed, uint64_t offset, uint64_t row_offset, int64_t* out, void* stream);
+
+/* ---- value function: MLPModel (problem/protein.py:58-121) --------------------------
+ * blob (fp32, device): time_embedder.0.W, time_embedder.1.{weight,bias}, embedder.{weight,bias},
+ * mlp.0.{weight,bias}, mlp.2.{weight,bias}, mlp.4.{weight,bias}, cls_head.0.{weight,bias},
+ * cls_head.2.{weight,bias}.  read_pos (host, [n_read]): the sequence positions the model reads
+ * (`seq[:, residues]`, problem/protein.py:108-109 -- the raw config list, defect D3; all
+ * positions when residues is None). */
+int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, const int* read_pos, int alphabet,
+                    int hidden, int time_conditioned, sgpo_mlp** out);
+void sgpo_mlp_destroy(sgpo_mlp* m);
+/* forward(seq, t): x [B][L], t [B] (NULL = zeros, log_likelihood of problem/protein.py:37-38) -> out [B] */
+int sgpo_mlp_forward(sgpo_mlp* m, const int64_t* x, const float* t, int B, int L, float* out, void* stream);
+/* Exact guidance log-ratios of get_guided_rates (models/mdlm.py:360-375, models/d3pm.py:146-161)
+ * in factored form: log_ratio [B][n_read][S] = f(x with x[read_pos[i]] <- s, t) - f(x, t).
+ * workspace: sgpo_mlp_workspace_bytes(B). */
+size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B);
+int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
+                            void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- test / bench access to the building blocks ----------------------------------- */
+/* C[M][N] (fp32) = A[M][K] (bf16) * W[N][K]^T (bf16) through the MFMA GEMM kernel. */
+int sgpo_gemm_bf16(const void* A, const void* W, float* C, int M, int N, int K, void* stream);
+int sgpo_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SGPO_HIP_H */

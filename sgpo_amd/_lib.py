@@ -1,0 +1,83 @@
+"""ctypes binding of libsgpo_hip.so (include/sgpo_hip.h).
+
+The product path has no CPU fallback: if the shared library is missing or a call
+fails, an exception is raised.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsgpo_hip.so')
+
+NOISE_PHILOX, NOISE_EXPONENTIAL, NOISE_UNIFORM = 0, 1, 2
+STEP_SOFT, STEP_SOFT_CG, STEP_HARD = 0, 1, 2
+
+
+class SgpoError(RuntimeError):
+    pass
+
+
+class DitConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('vocab', 'hidden', 'cond_dim', 'freq_dim', 'n_blocks', 'n_heads',
+                                       'mlp_hidden', 'max_len')]
+
+
+_vp, _i, _f, _u64, _sz, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_uint64, C.c_size_t, C.c_int64
+
+# name -> (restype, argtypes); must list every symbol include/sgpo_hip.h declares
+SIGNATURES = {
+    'sgpo_init': (_i, [_i]),
+    'sgpo_last_error': (C.c_char_p, []),
+    'sgpo_version': (_i, []),
+    'sgpo_dit_param_count': (_sz, [C.POINTER(DitConfig)]),
+    'sgpo_dit_create': (_i, [C.POINTER(DitConfig), _vp, _sz, C.POINTER(_vp)]),
+    'sgpo_dit_destroy': (None, [_vp]),
+    'sgpo_dit_workspace_bytes': (_sz, [_vp, _i, _i]),
+    'sgpo_dit_forward': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
+    'sgpo_reverse_step_mdlm': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _vp, _u64, _u64,
+                                    _u64, _vp, _vp, _vp, _vp]),
+    'sgpo_reverse_step_udlm': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    'sgpo_q_sample_mdlm': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp]),
+    'sgpo_categorical_sample': (_i, [_vp, _i64, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp]),
+    'sgpo_mlp_create': (_i, [_vp, _sz, _i, C.POINTER(_i), _i, _i, _i, C.POINTER(_vp)]),
+    'sgpo_mlp_destroy': (None, [_vp]),
+    'sgpo_mlp_forward': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
+    'sgpo_mlp_workspace_bytes': (_sz, [_vp, _i]),
+    'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'sgpo_gemm_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'sgpo_f32_to_bf16': (_i, [_vp, _vp, _sz, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise SgpoError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                            f'or `make -C sgpo_amd/csrc`. There is no CPU fallback.')
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what=''):
+    if rc != 0:
+        msg = load().sgpo_last_error().decode(errors='replace')
+        raise SgpoError(f'{what} failed ({rc}): {msg}')
+
+
+def ptr(t):
+    """Device/host address of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

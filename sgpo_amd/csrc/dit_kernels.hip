@@ -1,0 +1,342 @@
+// Non-GEMM kernels of the MDLM denoiser (DiT): conditioning MLP + adaLN tables,
+// embedding gather, LayerNorm+modulate, short-sequence attention.
+// Reference: models/pretraining/model/mdlm/models/dit.py (line refs per kernel).
+#include "common.h"
+#include "dit.h"
+
+// ---------------------------------------------------------------------------
+// RoPE tables  cos/sin[pos][i], i < head_dim/2   (dit.py:81-104: inv_freq = 1/10000^(2i/d))
+__global__ void rope_table_kernel(float* cs, float* sn, int max_len, int half) {
+  int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= max_len * half) return;
+  int pos = idx / half, i = idx % half;
+  float inv = 1.0f / powf(10000.0f, (float)(2 * i) / (float)(2 * half));
+  float a = (float)pos * inv;
+  cs[idx] = cosf(a);
+  sn[idx] = sinf(a);
+}
+
+// ---------------------------------------------------------------------------
+// c = silu(W2 silu(W1 emb(sigma) + b1) + b2)   (dit.py:150-189, :385), one block per sigma row.
+// Then every adaLN_modulation Linear (dit.py:232, :310): mod[row][j] = Wm[j,:] c + bm[j]
+// over the concatenated [n_blocks*6*H + 2*H] rows of all blocks + final layer.
+// The reference runs the adaLN Linear under bf16 autocast; here it is fp32 (closer to the
+// fp32 CPU oracle; DESIGN.md "precision contract").
+__global__ __launch_bounds__(256) void conditioning_kernel(const float* __restrict__ sigma, int n_sigma,
+                                                           const float* __restrict__ w1, const float* __restrict__ b1,
+                                                           const float* __restrict__ w2, const float* __restrict__ b2,
+                                                           int freq_dim, int cond_dim, float* __restrict__ c_out) {
+  extern __shared__ float sh[];  // emb[freq_dim] + h[cond_dim]
+  float* emb = sh;
+  float* h = sh + freq_dim;
+  const int row = blockIdx.x;
+  const float s = sigma ? sigma[row] : 0.f;
+  const int half = freq_dim / 2;
+  for (int i = threadIdx.x; i < half; i += blockDim.x) {
+    float f = expf(-logf(10000.f) * (float)i / (float)half);
+    emb[i] = cosf(s * f);
+    emb[half + i] = sinf(s * f);
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < cond_dim; j += blockDim.x) {
+    float a = b1[j];
+    for (int k = 0; k < freq_dim; ++k) a += w1[j * freq_dim + k] * emb[k];
+    h[j] = a / (1.f + expf(-a));
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < cond_dim; j += blockDim.x) {
+    float a = b2[j];
+    for (int k = 0; k < cond_dim; ++k) a += w2[j * cond_dim + k] * h[k];
+    c_out[row * cond_dim + j] = a / (1.f + expf(-a));
+  }
+}
+
+__global__ __launch_bounds__(256) void modulation_kernel(const float* __restrict__ c, int cond_dim,
+                                                         const float* __restrict__ wm, const float* __restrict__ bm,
+                                                         int n_out, float* __restrict__ mod) {
+  // grid (ceil(n_out/256), n_sigma)
+  extern __shared__ float cs[];
+  const int row = blockIdx.y;
+  for (int k = threadIdx.x; k < cond_dim; k += blockDim.x) cs[k] = c[row * cond_dim + k];
+  __syncthreads();
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n_out) return;
+  float a = bm[j];
+  const float* w = wm + (size_t)j * cond_dim;
+  for (int k = 0; k < cond_dim; ++k) a += w[k] * cs[k];
+  mod[(size_t)row * n_out + j] = a;
+}
+
+// ---------------------------------------------------------------------------
+// x0[m][:] = embedding[token[m]][:]   (dit.py:292-299), f32.  One wave per row, float4 lanes.
+__global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ tok, const float* __restrict__ emb,
+                                                    float* __restrict__ x, int M, int H, int vocab) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  int64_t t = tok[row];
+  if (t < 0) t = 0;
+  if (t >= vocab) t = vocab - 1;
+  const float4* src = reinterpret_cast<const float4*>(emb + (size_t)t * H);
+  float4* dst = reinterpret_cast<float4*>(x + (size_t)row * H);
+  for (int i = lane; i < H / 4; i += 64) dst[i] = src[i];
+}
+
+// ---------------------------------------------------------------------------
+// xn = LN(x) * w * (1 + scale[b]) + shift[b]  -> bf16   (dit.py:126-134, :46-49, :254, :286, :319)
+// LN: no bias, eps 1e-5, fp32 statistics.  One wave per row of H = 512 (8 floats per lane),
+// two-pass mean/variance in registers.  HBM-bound: 4H read + 2H written per row.
+template <int H>
+__global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                     const float* __restrict__ shift, const float* __restrict__ scale,
+                                                     int mod_stride, bf16_t* __restrict__ out, int M, int L, int B) {
+  constexpr int PER = H / 64;  // floats per lane
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  float v[PER];
+  const float* xr = x + (size_t)row * H;
+#pragma unroll
+  for (int i = 0; i < PER / 4; ++i) {
+    float4 t = reinterpret_cast<const float4*>(xr)[i * 64 + lane];
+    v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) s += v[i];
+  const float mean = wave_sum(s) * (1.0f / H);
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < PER; ++i) { float d = v[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+  int b = row / L;
+  if (b > B - 1) b = B - 1;
+  const float* sh = shift + (size_t)b * mod_stride;
+  const float* sc = scale + (size_t)b * mod_stride;
+#pragma unroll
+  for (int i = 0; i < PER / 4; ++i) {
+    const int col = (i * 64 + lane) * 4;
+    float4 ww = *reinterpret_cast<const float4*>(w + col);
+    float4 s4 = *reinterpret_cast<const float4*>(sh + col);
+    float4 c4 = *reinterpret_cast<const float4*>(sc + col);
+    float o0 = (v[i * 4 + 0] - mean) * rstd * ww.x * (1.f + c4.x) + s4.x;
+    float o1 = (v[i * 4 + 1] - mean) * rstd * ww.y * (1.f + c4.y) + s4.y;
+    float o2 = (v[i * 4 + 2] - mean) * rstd * ww.z * (1.f + c4.z) + s4.z;
+    float o3 = (v[i * 4 + 3] - mean) * rstd * ww.w * (1.f + c4.w) + s4.w;
+    uint2 pk;
+    pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
+    pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+    *reinterpret_cast<uint2*>(out + (size_t)row * H + col) = pk;
+  }
+}
+
+// Generic-H fallback (H % 256 == 0 not required): one wave per row, strided loop.
+__global__ __launch_bounds__(256) void ln_mod_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ shift, const float* __restrict__ scale,
+                                                             int mod_stride, bf16_t* __restrict__ out, int M, int L, int B, int H) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= M) return;
+  const int lane = threadIdx.x & 63;
+  const float* xr = x + (size_t)row * H;
+  float s = 0.f;
+  for (int i = lane; i < H; i += 64) s += xr[i];
+  const float mean = wave_sum(s) / (float)H;
+  float q = 0.f;
+  for (int i = lane; i < H; i += 64) { float d = xr[i] - mean; q += d * d; }
+  const float rstd = rsqrtf(wave_sum(q) / (float)H + 1e-5f);
+  int b = row / L;
+  if (b > B - 1) b = B - 1;
+  const float* sh = shift ? shift + (size_t)b * mod_stride : nullptr;
+  const float* sc = scale ? scale + (size_t)b * mod_stride : nullptr;
+  for (int i = lane; i < H; i += 64) {
+    float o = (xr[i] - mean) * rstd * w[i];
+    if (sc) o = o * (1.f + sc[i]) + sh[i];
+    out[(size_t)row * H + i] = f2bf(o);
+  }
+}
+
+int launch_ln_mod(const float* x, const float* w, const float* shift, const float* scale, int mod_stride,
+                  bf16_t* out, int M, int L, int B, int H, hipStream_t stream) {
+  dim3 grid((M + 3) / 4), block(256);
+  if (H == 512 && shift && scale)
+    hipLaunchKernelGGL(ln_mod_kernel<512>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B);
+  else if (H == 1024 && shift && scale)
+    hipLaunchKernelGGL(ln_mod_kernel<1024>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B);
+  else
+    hipLaunchKernelGGL(ln_mod_generic_kernel, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B, H);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// Non-causal multi-head attention for short fixed-length sequences (L <= 512), head_dim 64.
+// Replaces flash_attn_varlen_qkvpacked_func (dit.py:272-273) for equal-length sequences.
+//
+// One workgroup (4 waves) per (sequence, head).  K [Lp][64] (XOR-swizzled 16-B chunks) and
+// V^T [64][Lp+4] live in LDS for the whole sequence.  A wave owns 32-query tiles and walks the
+// key tiles with an online softmax.  Products are "swapped" so every per-query quantity
+// (max, sum, rescale) is lane-local:
+//     S^T[key][query] = K Q^T          A = K rows (LDS),  B = Q (registers)
+//     O^T[d][query]  += V^T P^T        A = V^T rows (LDS), B = the S^T accumulator itself,
+//                                      converted to bf16 in place (k order of the accumulator).
+// qkv: [M][3*Hd] bf16 (q | k | v sections, heads contiguous inside a section), RoPE already applied.
+#define ATT_D 64
+
+__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                        int L, int Lp, int n_heads, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int hid = n_heads * ATT_D;
+  const int ld = 3 * hid;
+  const int b = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 31, lh = lane >> 5;
+  const int vt_stride = Lp + 4;  // bf16 elements; (Lp/2 + 2) dwords = 2*odd -> conflict-free b64 reads
+  char* k_lds = smem;                                            // Lp * 128 B
+  bf16_t* vt_lds = reinterpret_cast<bf16_t*>(smem + Lp * 128);   // 64 * vt_stride
+  const bf16_t* base = qkv + (size_t)b * L * ld + h * ATT_D;
+
+  // ---- stage K (swizzled rows) and V^T; rows >= L are zero
+  for (int idx = tid; idx < Lp * 8; idx += 256) {
+    const int row = idx >> 3, c = idx & 7;
+    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
+    if (row < L) {
+      kv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + hid + c * 8);
+      vv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * hid + c * 8);
+    }
+    *reinterpret_cast<uint4*>(k_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
+    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * vt_stride + row] = ve[i];
+  }
+  __syncthreads();
+
+  const int n_tiles = Lp / 32;
+  for (int qt = wave; qt < n_tiles; qt += 4) {
+    // Q fragments: B operand, lane holds Q[query = qt*32+lr][d = kk*16 + 8*lh + j]
+    int qrow = qt * 32 + lr;
+    if (qrow > L - 1) qrow = L - 1;
+    bf16x8 qf[4];
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
+
+    f32x16 o0, o1;  // O^T tiles: d in [0,32), [32,64); column = query (lane)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
+    float m_run = -1e30f, l_run = 0.f;
+
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      f32x16 s;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s[r] = 0.f;
+      const int krow = kt * 32 + lr;
+      const char* kr = k_lds + krow * 128;
+      const int sw = (krow >> 1) & 7;
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (((kk * 2 + lh) ^ sw) << 4));
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+      }
+      // s[r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*lh][query = lr]  (unscaled)
+      float tmax = -1e30f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        s[r] = (key < L) ? s[r] * scale_log2e : -1e30f;
+        tmax = fmaxf(tmax, s[r]);
+      }
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      const float m_new = fmaxf(m_run, tmax);
+      const float alpha = exp2f(m_run - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - m_new); psum += s[r]; }
+      psum += __shfl_xor(psum, 32);
+      l_run = l_run * alpha + psum;
+      m_run = m_new;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      // P^T as the B operand of the next product: k-step st uses registers 8st..8st+7; element j of
+      // lane-half lh is key 16st + 8(j>>2) + 4 lh + (j&3) of this tile.
+#pragma unroll
+      for (int st = 0; st < 2; ++st) {
+        bf16x8 pf;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[st * 8 + j];
+        const int kbase = kt * 32 + st * 16 + lh * 4;
+        // A operand: V^T[d = lr (+32)][same keys]: two 8-byte reads (keys kbase..+3, kbase+8..+11)
+        bf16x8 v0, v1;
+        {
+          const bf16_t* r0 = vt_lds + lr * vt_stride + kbase;
+          const bf16_t* r1 = vt_lds + (lr + 32) * vt_stride + kbase;
+          bf16x4 a = *reinterpret_cast<const bf16x4*>(r0);
+          bf16x4 c = *reinterpret_cast<const bf16x4*>(r0 + 8);
+          bf16x4 d = *reinterpret_cast<const bf16x4*>(r1);
+          bf16x4 e = *reinterpret_cast<const bf16x4*>(r1 + 8);
+          v0 = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+          v1 = __builtin_shufflevector(d, e, 0, 1, 2, 3, 4, 5, 6, 7);
+        }
+        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o0, 0, 0, 0);
+        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o1, 0, 0, 0);
+      }
+    }
+    // ---- write O[query][d] = O^T / l ; lane owns query qt*32+lr, rows d = (r&3)+8(r>>2)+4lh (+32)
+    const int q = qt * 32 + lr;
+    if (q < L) {
+      const float inv = 1.0f / l_run;
+      bf16_t* orow = out + ((size_t)b * L + q) * hid + h * ATT_D;
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int d = 8 * g + 4 * lh;
+        uint2 p0, p1;
+        p0.x = (uint32_t)f2bf(o0[g * 4 + 0] * inv) | ((uint32_t)f2bf(o0[g * 4 + 1] * inv) << 16);
+        p0.y = (uint32_t)f2bf(o0[g * 4 + 2] * inv) | ((uint32_t)f2bf(o0[g * 4 + 3] * inv) << 16);
+        p1.x = (uint32_t)f2bf(o1[g * 4 + 0] * inv) | ((uint32_t)f2bf(o1[g * 4 + 1] * inv) << 16);
+        p1.y = (uint32_t)f2bf(o1[g * 4 + 2] * inv) | ((uint32_t)f2bf(o1[g * 4 + 3] * inv) << 16);
+        *reinterpret_cast<uint2*>(orow + d) = p0;
+        *reinterpret_cast<uint2*>(orow + 32 + d) = p1;
+      }
+    }
+  }
+}
+
+int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, int head_dim, hipStream_t stream) {
+  SGPO_REQUIRE(head_dim == ATT_D, "attention: head_dim %d unsupported (64 only)", head_dim);
+  const int Lp = (L + 31) / 32 * 32;
+  const size_t lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 4) * 2;
+  SGPO_REQUIRE(lds <= 160 * 1024, "attention: sequence length %d exceeds the LDS-resident limit", L);
+  static size_t attr_lds = 0;
+  if (lds > attr_lds) {
+    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    attr_lds = lds;
+  }
+  const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+  hipLaunchKernelGGL(attention_kernel, dim3(B * n_heads), dim3(256), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+int launch_embed(const int64_t* tok, const float* emb, float* x, int M, int H, int vocab, hipStream_t stream) {
+  hipLaunchKernelGGL(embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tok, emb, x, M, H, vocab);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+int launch_rope_table(float* cs, float* sn, int max_len, int half, hipStream_t stream) {
+  const int n = max_len * half;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, cs, sn, max_len, half);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+int launch_conditioning(const float* sigma, int n_sigma, const float* w1, const float* b1, const float* w2,
+                        const float* b2, int freq_dim, int cond_dim, float* c_out, const float* wm,
+                        const float* bm, int n_out, float* mod, hipStream_t stream) {
+  hipLaunchKernelGGL(conditioning_kernel, dim3(n_sigma), dim3(256), (freq_dim + cond_dim) * sizeof(float), stream,
+                     sigma, n_sigma, w1, b1, w2, b2, freq_dim, cond_dim, c_out);
+  hipLaunchKernelGGL(modulation_kernel, dim3((n_out + 255) / 256, n_sigma), dim3(256), cond_dim * sizeof(float),
+                     stream, c_out, cond_dim, wm, bm, n_out, mod);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}

@@ -1,0 +1,260 @@
+// bf16 MFMA GEMM with fused epilogues -- see gemm.h for the design notes.
+#include "gemm.h"
+
+#define BM 128
+#define BN 128
+#define BK 64
+#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand tile
+
+typedef const __attribute__((address_space(1))) void* gptr_t;
+typedef __attribute__((address_space(3))) void* lptr_t;
+
+struct GemmSeg {
+  int n_seg;       // K = n_seg * seg_k ; segment s reads A rows shifted by shift[s]
+  int seg_k;
+  int shift[8];
+};
+
+__device__ __forceinline__ float gelu_tanh_f(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
+  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
+  float e = __expf(2.0f * u);
+  float t = 1.0f - 2.0f / (e + 1.0f);
+  return 0.5f * x * (1.0f + t);
+}
+__device__ __forceinline__ float gelu_erf_f(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile + B tile)
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+
+  // XCD-aware block remap: blocks that share an XCD (id % 8) get a contiguous run of tiles,
+  // N-tiles fastest, so an A row-panel is re-read from that XCD's L2.
+  const int ntn = (p.N + BN - 1) / BN;
+  const int nwg = gridDim.x;
+  int bid = blockIdx.x;
+  {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  const int m0 = (bid / ntn) * BM;
+  const int n0 = (bid % ntn) * BN;
+
+  // ---- per-lane staging coordinates (4 LDS-DMA instructions per operand per wave)
+  const bf16_t* a_src[4];
+  int a_l[4];
+  const bf16_t* w_src[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wave * 4 + j;
+    const int row = i * 8 + (lane >> 3);
+    const int pc = lane & 7;
+    const int c = pc ^ ((row >> 1) & 7);
+    int m = m0 + row;
+    if (m > p.M - 1) m = p.M - 1;
+    a_src[j] = p.A + (size_t)m * p.lda + c * 8;
+    a_l[j] = m % p.L;
+    int n = n0 + row;
+    if (n > p.N - 1) n = p.N - 1;
+    w_src[j] = p.W + (size_t)n * p.ldw + c * 8;
+  }
+
+  auto stage = [&](int buf, int kt) {
+    const int kglob = kt * BK;
+    const int seg = kglob / sg.seg_k;
+    const int kin = kglob - seg * sg.seg_k;
+    const int sh = sg.shift[seg];
+    char* abase = smem + buf * (2 * TILE_BYTES);
+    char* bbase = abase + TILE_BYTES;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave * 4 + j;
+      const bf16_t* src = a_src[j] + (ptrdiff_t)sh * p.lda + kin;
+      const int lp = a_l[j] + sh;
+      if (lp < 0 || lp >= p.L) src = zero16;  // zero padding at the sequence ends (conv taps)
+      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + i * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int i = wave * 4 + j;
+      __builtin_amdgcn_global_load_lds((gptr_t)(w_src[j] + kglob), (lptr_t)(bbase + i * 1024), 16, 0, 0);
+    }
+  };
+
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  // fragment read offsets (bytes inside a tile): row*128 + ((c ^ ((row>>1)&7)) * 16)
+  const int lr = lane & 31, lh = lane >> 5;
+  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int ra = wr * 64 + t * 32 + lr;
+    const int rb = wc * 64 + t * 32 + lr;
+    a_off[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
+    b_off[t] = rb * 128; b_sw[t] = (rb >> 1) & 7;
+  }
+
+  const int nk = p.K / BK;
+  stage(0, 0);
+  for (int kt = 0; kt < nk; ++kt) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
+    const char* abase = smem + (kt & 1) * (2 * TILE_BYTES);
+    const char* bbase = abase + TILE_BYTES;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int c = kk * 2 + lh;
+      bf16x8 af[2], bfr[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        af[t] = *reinterpret_cast<const bf16x8*>(abase + a_off[t] + ((c ^ a_sw[t]) << 4));
+        bfr[t] = *reinterpret_cast<const bf16x8*>(bbase + b_off[t] + ((c ^ b_sw[t]) << 4));
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+    }
+  }
+
+  // ---------------------------------------------------------------- epilogue
+  // D[row = (r&3) + 8*(r>>2) + 4*lh][col = lr]
+  const int ncol0 = n0 + wc * 64;
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (m >= p.M) continue;
+      float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
+      const int na = ncol0 + lr, nb = ncol0 + 32 + lr;
+      if constexpr (EPI == EPI_QKV_ROPE) {
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        if (ncol0 < p.rope_cols) {  // wave-uniform: a whole head (64 cols) of q or k
+          const int pos = m % p.L;
+          const float cs = p.rope_cos[pos * (p.head_dim / 2) + lr];
+          const float sn = p.rope_sin[pos * (p.head_dim / 2) + lr];
+          const float o0 = v0 * cs - v1 * sn;
+          const float o1 = v0 * sn + v1 * cs;
+          v0 = o0; v1 = o1;
+        }
+        C[(size_t)m * p.ldc + na] = f2bf(v0);
+        C[(size_t)m * p.ldc + nb] = f2bf(v1);
+      } else if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ERF) {
+        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        if (p.bias) { v0 += p.bias[na]; v1 += p.bias[nb]; }
+        if constexpr (EPI == EPI_BIAS_GELU) { v0 = gelu_tanh_f(v0); v1 = gelu_tanh_f(v1); }
+        if constexpr (EPI == EPI_BIAS_GELU_ERF) { v0 = gelu_erf_f(v0); v1 = gelu_erf_f(v1); }
+        C[(size_t)m * p.ldc + na] = f2bf(v0);
+        C[(size_t)m * p.ldc + nb] = f2bf(v1);
+      } else if constexpr (EPI == EPI_GATE_RES || EPI == EPI_RES) {
+        float* C = reinterpret_cast<float*>(p.C);
+        if (p.bias) { v0 += p.bias[na]; v1 += p.bias[nb]; }
+        if constexpr (EPI == EPI_GATE_RES) {
+          int b = m / p.L;
+          if (b > p.B - 1) b = p.B - 1;
+          const float* g = p.gate + (size_t)b * p.gate_stride;
+          v0 *= g[na]; v1 *= g[nb];
+        }
+        C[(size_t)m * p.ldc + na] = p.xin[(size_t)m * p.ldc + na] + v0;
+        C[(size_t)m * p.ldc + nb] = p.xin[(size_t)m * p.ldc + nb] + v1;
+      } else {  // EPI_BIAS_F32 / EPI_ACC_F32
+        float* C = reinterpret_cast<float*>(p.C);
+        if (na < p.N) {
+          if (p.bias) v0 += p.bias[na];
+          if constexpr (EPI == EPI_ACC_F32) v0 += C[(size_t)m * p.ldc + na];
+          C[(size_t)m * p.ldc + na] = v0;
+        }
+        if (nb < p.N) {
+          if (p.bias) v1 += p.bias[nb];
+          if constexpr (EPI == EPI_ACC_F32) v1 += C[(size_t)m * p.ldc + nb];
+          C[(size_t)m * p.ldc + nb] = v1;
+        }
+      }
+    }
+  }
+}
+
+static const bf16_t* g_zero16[16] = {nullptr};
+
+static int get_zero16(const bf16_t** out) {
+  int dev = 0;
+  SGPO_CHECK_HIP(hipGetDevice(&dev));
+  if (dev < 0 || dev >= 16) { sgpo_set_error("device index %d out of range", dev); return SGPO_ERR_ARG; }
+  if (!g_zero16[dev]) {
+    void* z = nullptr;
+    SGPO_CHECK_HIP(hipMalloc(&z, 256));
+    SGPO_CHECK_HIP(hipMemset(z, 0, 256));
+    g_zero16[dev] = reinterpret_cast<const bf16_t*>(z);
+  }
+  *out = g_zero16[dev];
+  return SGPO_OK;
+}
+
+extern "C" int sgpo_gemm_init_device() {  // called from sgpo_init: allocates the zero page once
+  const bf16_t* z;
+  return get_zero16(&z);
+}
+
+int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, const int* shifts, hipStream_t stream) {
+  SGPO_REQUIRE(p.M > 0 && p.N > 0 && p.K > 0, "gemm: empty problem M=%d N=%d K=%d", p.M, p.N, p.K);
+  SGPO_REQUIRE(p.K % BK == 0, "gemm: K=%d must be a multiple of %d", p.K, BK);
+  SGPO_REQUIRE(n_seg >= 1 && n_seg <= 8 && seg_k % BK == 0 && n_seg * seg_k == p.K, "gemm: bad K segmentation");
+  SGPO_REQUIRE(p.L > 0, "gemm: L must be positive");
+  SGPO_REQUIRE((p.lda % 8) == 0 && (p.ldw % 8) == 0, "gemm: lda/ldw must be multiples of 8 elements (16-B rows)");
+  if (epi != EPI_BIAS_F32 && epi != EPI_ACC_F32)
+    SGPO_REQUIRE(p.N % 64 == 0, "gemm: N=%d must be a multiple of 64 for this epilogue", p.N);
+  GemmSeg sg;
+  sg.n_seg = n_seg; sg.seg_k = seg_k;
+  for (int i = 0; i < 8; ++i) sg.shift[i] = (shifts && i < n_seg) ? shifts[i] : 0;
+  const bf16_t* z = nullptr;
+  int rc = get_zero16(&z);
+  if (rc) return rc;
+  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  dim3 grid(ntm * ntn), block(256);
+  const size_t lds = 4 * TILE_BYTES;
+#define LAUNCH(E)                                                                                   \
+  case E: {                                                                                         \
+    static bool attr_set = false;                                                                   \
+    if (!attr_set) {                                                                                \
+      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<E>),        \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+      attr_set = true;                                                                              \
+    }                                                                                               \
+    hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, lds, stream, p, sg, z);                    \
+  } break;
+  switch (epi) {
+    LAUNCH(EPI_BF16)
+    LAUNCH(EPI_QKV_ROPE)
+    LAUNCH(EPI_GATE_RES)
+    LAUNCH(EPI_BIAS_GELU)
+    LAUNCH(EPI_BIAS_F32)
+    LAUNCH(EPI_BIAS_GELU_ERF)
+    LAUNCH(EPI_RES)
+    LAUNCH(EPI_ACC_F32)
+    default:
+      sgpo_set_error("gemm: unknown epilogue %d", epi);
+      return SGPO_ERR_ARG;
+  }
+#undef LAUNCH
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+int launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream) {
+  return launch_gemm_bf16_seg(p, epi, 1, p.K, nullptr, stream);
+}

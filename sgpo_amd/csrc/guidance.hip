@@ -1,0 +1,326 @@
+// Value-function kernels: MLPModel forward and the exact-guidance jump log-ratios in
+// factored (rank-1 update) form.
+//
+// Reference: problem/protein.py:58-121 (MLPModel), models/mdlm.py:111-162,360-375 and
+// models/d3pm.py:55-106,146-161 (all single-site jumps, materialised as B*D*S x D there).
+//
+// A jump changes one one-hot row, so the first Linear's pre-activation moves by a table
+// difference:  pre(x with x_d <- s) = pre(x) + T1[d][s] - T1[d][x_d],
+//   T1[i][s][:] = W1[:, i*h:(i+1)*h] @ E[:, s]      (E = embedder.weight, bias folded into be1)
+// The table (n_read x alphabet x 64 fp32, <= 944 KB) is L2-resident.  The 64x64 tails run on
+// the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain), one 32-lane
+// tile = the 31(+1) jumps of one (sequence, read position), "transposed" so that the
+// activation accumulator of one layer is the B operand of the next with no data movement.
+#include <vector>
+
+#include "../../include/sgpo_hip.h"
+#include "common.h"
+
+#define MH 64  // hidden width (problem/protein.py: hidden_dim 64)
+
+struct sgpo_mlp {
+  int n_read = 0, alphabet = 0, hidden = 0, time_cond = 0;
+  int* read_pos = nullptr;     // [n_read] device
+  float* params = nullptr;     // raw blob copy
+  float* T1 = nullptr;         // [n_read][alphabet][64]
+  float* be1 = nullptr;        // [64] b1 + sum_i W1_i be
+  float* w1t_time = nullptr;   // [k][j] = W1[j][n_read*64 + k]
+  float* wt_lin_t = nullptr;   // [k][j] = time_embedder.1.weight[j][k]
+  float* w_t[3] = {nullptr, nullptr, nullptr};  // transposed 64x64 layers (mlp.2, mlp.4, cls_head.0): [k][j]
+  float* w_perm = nullptr;     // the three layers permuted for the MFMA A operand: [layer][to][ti][r][h][i]
+  float* bias_perm = nullptr;  // [layer][t][r][h] biases in accumulator order (3 layers) + w5 in the same order
+  const float *tW, *bt, *b2, *b3, *b4, *w5, *b5;
+};
+
+// ---- setup kernels ---------------------------------------------------------
+__global__ void mlp_table_kernel(const float* __restrict__ W1, int in_dim, const float* __restrict__ E /*[64][A]*/,
+                                 int A, int n_read, float* __restrict__ T1) {
+  // T1[i][s][j] = sum_k W1[j][i*64+k] * E[k][s]
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= n_read * A * MH) return;
+  const int j = idx % MH, s = (idx / MH) % A, i = idx / (MH * A);
+  const float* w = W1 + (size_t)j * in_dim + i * MH;
+  float a = 0.f;
+  for (int k = 0; k < MH; ++k) a = fmaf(w[k], E[k * A + s], a);
+  T1[idx] = a;
+}
+__global__ void mlp_bias_kernel(const float* __restrict__ W1, int in_dim, const float* __restrict__ be,
+                                const float* __restrict__ b1, int n_read, float* __restrict__ be1) {
+  const int j = threadIdx.x;
+  if (j >= MH) return;
+  const float* w = W1 + (size_t)j * in_dim;
+  float a = 0.f;
+  for (int k = 0; k < n_read * MH; ++k) a = fmaf(w[k], be[k % MH], a);
+  be1[j] = b1[j] + a;
+}
+__global__ void transpose_kernel(const float* __restrict__ src, int ld, int col0, float* __restrict__ dst) {
+  // dst[k][j] = src[j][col0 + k], 64x64
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= MH * MH) return;
+  const int k = idx / MH, j = idx % MH;
+  dst[idx] = src[(size_t)j * ld + col0 + k];
+}
+__device__ __host__ inline int acc_unit(int t, int r, int h) { return 32 * t + (r & 3) + 8 * (r >> 2) + 4 * h; }
+__global__ void permute_layer_kernel(const float* __restrict__ W /*[64][64] row-major [out][in]*/, float* __restrict__ dst) {
+  // dst[to][ti][r][h][i] = W[32 to + i][unit(ti, r, h)]
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= MH * MH) return;
+  const int i = idx & 31, h = (idx >> 5) & 1, r = (idx >> 6) & 15, ti = (idx >> 10) & 1, to = (idx >> 11) & 1;
+  dst[idx] = W[(32 * to + i) * MH + acc_unit(ti, r, h)];
+}
+__global__ void permute_bias_kernel(const float* __restrict__ b, float* __restrict__ dst) {
+  // dst[t][r][h] = b[unit(t, r, h)]
+  const int idx = threadIdx.x;
+  if (idx >= MH) return;
+  const int h = idx & 1, r = (idx >> 1) & 15, t = idx >> 5;
+  dst[idx] = b[acc_unit(t, r, h)];
+}
+
+extern "C" void sgpo_mlp_destroy(sgpo_mlp* m) {
+  if (!m) return;
+  (void)hipFree(m->read_pos); (void)hipFree(m->params); (void)hipFree(m->T1); (void)hipFree(m->be1);
+  (void)hipFree(m->w1t_time); (void)hipFree(m->wt_lin_t);
+  for (int i = 0; i < 3; ++i) (void)hipFree(m->w_t[i]);
+  (void)hipFree(m->w_perm); (void)hipFree(m->bias_perm);
+  delete m;
+}
+
+extern "C" int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, const int* read_pos, int alphabet,
+                               int hidden, int time_conditioned, sgpo_mlp** out) {
+  SGPO_REQUIRE(blob && read_pos && out, "mlp_create: null argument");
+  SGPO_REQUIRE(hidden == MH, "mlp_create: hidden_dim %d unsupported (64 only)", hidden);
+  SGPO_REQUIRE(n_read > 0 && alphabet > 0 && alphabet <= 32, "mlp_create: n_read=%d alphabet=%d (alphabet <= 32)", n_read, alphabet);
+  const size_t h = MH, A = alphabet;
+  const size_t in_dim = h * (n_read + (time_conditioned ? 1 : 0));
+  const size_t expect = h / 2 + h * h + h + h * A + h + h * in_dim + h + 3 * (h * h + h) + h + 1;
+  SGPO_REQUIRE(n_floats == expect, "mlp_create: blob has %zu floats, expected %zu", n_floats, expect);
+  sgpo_mlp* m = new sgpo_mlp();
+  m->n_read = n_read; m->alphabet = alphabet; m->hidden = hidden; m->time_cond = time_conditioned;
+#define HIPF(e) do { hipError_t _e = (e); if (_e != hipSuccess) { sgpo_set_error("%s: %s", #e, hipGetErrorString(_e)); sgpo_mlp_destroy(m); return SGPO_ERR_HIP; } } while (0)
+  HIPF(hipMalloc((void**)&m->params, n_floats * 4));
+  HIPF(hipMemcpy(m->params, blob, n_floats * 4, hipMemcpyDeviceToDevice));
+  HIPF(hipMalloc((void**)&m->read_pos, n_read * sizeof(int)));
+  HIPF(hipMemcpy(m->read_pos, read_pos, n_read * sizeof(int), hipMemcpyHostToDevice));
+  HIPF(hipMalloc((void**)&m->T1, (size_t)n_read * A * h * 4));
+  HIPF(hipMalloc((void**)&m->be1, h * 4));
+  HIPF(hipMalloc((void**)&m->w1t_time, h * h * 4));
+  HIPF(hipMalloc((void**)&m->wt_lin_t, h * h * 4));
+  for (int i = 0; i < 3; ++i) HIPF(hipMalloc((void**)&m->w_t[i], h * h * 4));
+  HIPF(hipMalloc((void**)&m->w_perm, 3 * h * h * 4));
+  HIPF(hipMalloc((void**)&m->bias_perm, 4 * h * 4));
+  const float* p = m->params;
+  auto take = [&](size_t n) { const float* r = p; p += n; return r; };
+  m->tW = take(h / 2);
+  const float* wt_lin = take(h * h); m->bt = take(h);
+  const float* E = take(h * A); const float* be = take(h);
+  const float* W1 = take(h * in_dim); const float* b1 = take(h);
+  const float* W2 = take(h * h); m->b2 = take(h);
+  const float* W3 = take(h * h); m->b3 = take(h);
+  const float* W4 = take(h * h); m->b4 = take(h);
+  m->w5 = take(h); m->b5 = take(1);
+  const int nT = n_read * (int)A * MH;
+  hipLaunchKernelGGL(mlp_table_kernel, dim3((nT + 255) / 256), dim3(256), 0, 0, W1, (int)in_dim, E, (int)A, n_read, m->T1);
+  hipLaunchKernelGGL(mlp_bias_kernel, dim3(1), dim3(64), 0, 0, W1, (int)in_dim, be, b1, n_read, m->be1);
+  if (time_conditioned)
+    hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, 0, W1, (int)in_dim, n_read * MH, m->w1t_time);
+  hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, 0, wt_lin, MH, 0, m->wt_lin_t);
+  const float* Ws[3] = {W2, W3, W4};
+  const float* bs[4] = {m->b2, m->b3, m->b4, m->w5};
+  for (int i = 0; i < 3; ++i) {
+    hipLaunchKernelGGL(transpose_kernel, dim3(16), dim3(256), 0, 0, Ws[i], MH, 0, m->w_t[i]);
+    hipLaunchKernelGGL(permute_layer_kernel, dim3(16), dim3(256), 0, 0, Ws[i], m->w_perm + (size_t)i * h * h);
+  }
+  for (int i = 0; i < 4; ++i)
+    hipLaunchKernelGGL(permute_bias_kernel, dim3(1), dim3(64), 0, 0, bs[i], m->bias_perm + i * MH);
+  HIPF(hipGetLastError());
+  HIPF(hipDeviceSynchronize());
+#undef HIPF
+  *out = m;
+  return SGPO_OK;
+}
+
+// ---- forward of one sequence per wave (VALU; also yields the layer-1 pre-activation) -------
+struct MlpDev {
+  const int* read_pos; const float* T1; const float* be1; const float* w1t_time; const float* wt_lin_t;
+  const float* w2t; const float* w3t; const float* w4t;
+  const float *tW, *bt, *b2, *b3, *b4, *w5, *b5;
+  int n_read, alphabet, time_cond;
+};
+
+__global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* __restrict__ x, const float* __restrict__ t,
+                                                      float t_scalar, int L, float* __restrict__ hpre,
+                                                      float* __restrict__ fout) {
+  __shared__ float buf[2][MH];
+  const int b = blockIdx.x, j = threadIdx.x;
+  float pre = d.be1[j];
+  if (d.time_cond) {
+    const float tv = t ? t[b] : t_scalar;
+    // GaussianFourierProjection (problem/protein.py:54-56): x*W*2*pi, cat(sin, cos)
+    const float arg = tv * d.tW[j & 31] * 2.0f * 3.14159274101257324f;
+    buf[0][j] = (j < 32) ? sinf(arg) : cosf(arg);
+    __syncthreads();
+    float te = d.bt[j];
+    for (int k = 0; k < MH; ++k) te = fmaf(d.wt_lin_t[k * MH + j], buf[0][k], te);
+    buf[1][j] = te;
+    __syncthreads();
+    for (int k = 0; k < MH; ++k) pre = fmaf(d.w1t_time[k * MH + j], buf[1][k], pre);
+    __syncthreads();
+  }
+  const int64_t* xr = x + (size_t)b * L;
+  for (int i = 0; i < d.n_read; ++i) {
+    int tok = (int)xr[d.read_pos[i]];
+    tok = tok < 0 ? 0 : (tok >= d.alphabet ? d.alphabet - 1 : tok);
+    pre += d.T1[((size_t)i * d.alphabet + tok) * MH + j];
+  }
+  if (hpre) hpre[(size_t)b * MH + j] = pre;
+  if (!fout) return;
+  buf[0][j] = fmaxf(pre, 0.f);
+  __syncthreads();
+  float a = d.b2[j];
+  for (int k = 0; k < MH; ++k) a = fmaf(d.w2t[k * MH + j], buf[0][k], a);
+  buf[1][j] = fmaxf(a, 0.f);
+  __syncthreads();
+  a = d.b3[j];
+  for (int k = 0; k < MH; ++k) a = fmaf(d.w3t[k * MH + j], buf[1][k], a);
+  buf[0][j] = a;
+  __syncthreads();
+  a = d.b4[j];
+  for (int k = 0; k < MH; ++k) a = fmaf(d.w4t[k * MH + j], buf[0][k], a);
+  a = fmaxf(a, 0.f) * d.w5[j];
+  a = wave_sum(a);
+  if (j == 0) fout[b] = a + d.b5[0];
+}
+
+static MlpDev mlp_dev(const sgpo_mlp* m) {
+  MlpDev d;
+  d.read_pos = m->read_pos; d.T1 = m->T1; d.be1 = m->be1; d.w1t_time = m->w1t_time; d.wt_lin_t = m->wt_lin_t;
+  d.w2t = m->w_t[0]; d.w3t = m->w_t[1]; d.w4t = m->w_t[2];
+  d.tW = m->tW; d.bt = m->bt; d.b2 = m->b2; d.b3 = m->b3; d.b4 = m->b4; d.w5 = m->w5; d.b5 = m->b5;
+  d.n_read = m->n_read; d.alphabet = m->alphabet; d.time_cond = m->time_cond;
+  return d;
+}
+
+extern "C" int sgpo_mlp_forward(sgpo_mlp* m, const int64_t* x, const float* t, int B, int L, float* out, void* stream) {
+  SGPO_REQUIRE(m && x && out, "mlp_forward: null argument");
+  SGPO_REQUIRE(B > 0 && L > 0, "mlp_forward: B=%d L=%d", B, L);
+  hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mlp_dev(m), x, t, 0.f, L,
+                     (float*)nullptr, out);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// ---- jump kernel --------------------------------------------------------------------
+// One wave-tile = the S (<= 32) jumps of one (sequence b, read slot i); lane column = target
+// state s, both lane halves hold complementary halves of the 64 hidden units in accumulator
+// order unit(t, r, h) = 32 t + (r&3) + 8 (r>>2) + 4 h.
+__device__ __forceinline__ void mfma_layer(const float* __restrict__ wl /*LDS [to][ti][r][h][i]*/, const f32x16 (&in)[2],
+                                           f32x16 (&out)[2], int lane) {
+#pragma unroll
+  for (int to = 0; to < 2; ++to) {
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ti = 0; ti < 2; ++ti)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float a = wl[((to * 2 + ti) * 16 + r) * 64 + lane];  // [h][i] == lane order
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, in[ti][r], acc, 0, 0, 0);
+      }
+    out[to] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restrict__ w_perm, const float* __restrict__ bias_perm,
+                                                       const float* __restrict__ T1, const int* __restrict__ read_pos,
+                                                       const float* __restrict__ hpre, const int64_t* __restrict__ x,
+                                                       float b5, int n_tiles, int n_read, int alphabet, int S, int L,
+                                                       float* __restrict__ log_ratio) {
+  __shared__ float wl[3 * MH * MH];
+  __shared__ float bl[4 * MH];
+  for (int i = threadIdx.x; i < 3 * MH * MH; i += 256) wl[i] = w_perm[i];
+  for (int i = threadIdx.x; i < 4 * MH; i += 256) bl[i] = bias_perm[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int s = lane & 31, h = lane >> 5;
+  const int n_waves = gridDim.x * 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+    const int b = tile / n_read, i = tile % n_read;
+    int xi = (int)x[(size_t)b * L + read_pos[i]];
+    xi = xi < 0 ? 0 : (xi >= alphabet ? alphabet - 1 : xi);
+    const int sc = s < S ? s : S - 1;
+    const float* hp = hpre + (size_t)b * MH;
+    const float* tn = T1 + ((size_t)i * alphabet + sc) * MH;
+    const float* to_ = T1 + ((size_t)i * alphabet + xi) * MH;
+    f32x16 a[2], o[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int u = 32 * t + 8 * g + 4 * h;
+        const float4 p4 = *reinterpret_cast<const float4*>(hp + u);
+        const float4 n4 = *reinterpret_cast<const float4*>(tn + u);
+        const float4 o4 = *reinterpret_cast<const float4*>(to_ + u);
+        const bool same = (sc == xi);  // identity jump: exactly f(x)
+        a[t][g * 4 + 0] = fmaxf(same ? p4.x : (p4.x + n4.x - o4.x), 0.f);
+        a[t][g * 4 + 1] = fmaxf(same ? p4.y : (p4.y + n4.y - o4.y), 0.f);
+        a[t][g * 4 + 2] = fmaxf(same ? p4.z : (p4.z + n4.z - o4.z), 0.f);
+        a[t][g * 4 + 3] = fmaxf(same ? p4.w : (p4.w + n4.w - o4.w), 0.f);
+      }
+    // mlp.2 + ReLU
+    mfma_layer(wl, a, o, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[t][r] = fmaxf(o[t][r] + bl[0 * MH + (t * 16 + r) * 2 + h], 0.f);
+    // mlp.4 (no activation)
+    mfma_layer(wl + MH * MH, o, a, lane);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) a[t][r] = a[t][r] + bl[1 * MH + (t * 16 + r) * 2 + h];
+    // cls_head.0 + ReLU
+    mfma_layer(wl + 2 * MH * MH, a, o, lane);
+    float f = 0.f;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const float v = fmaxf(o[t][r] + bl[2 * MH + (t * 16 + r) * 2 + h], 0.f);
+        f = fmaf(v, bl[3 * MH + (t * 16 + r) * 2 + h], f);
+      }
+    f += __shfl_xor(f, 32);
+    f += b5;
+    const float fbase = __shfl(f, xi);
+    if (h == 0 && s < S) log_ratio[((size_t)b * n_read + i) * S + s] = (s == xi) ? 0.f : f - fbase;
+  }
+}
+
+extern "C" size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B) {
+  if (!m || B <= 0) return 0;
+  return ((size_t)B * MH * sizeof(float) + 255) & ~(size_t)255;
+}
+
+extern "C" int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  SGPO_REQUIRE(m && x && log_ratio && workspace, "guidance_ratio_mlp: null argument");
+  SGPO_REQUIRE(B > 0 && L > 0 && S > 0 && S <= 32 && S <= m->alphabet, "guidance_ratio_mlp: B=%d L=%d S=%d (S <= min(32, alphabet))", B, L, S);
+  if (workspace_bytes < sgpo_mlp_workspace_bytes(m, B)) {
+    sgpo_set_error("guidance_ratio_mlp: workspace %zu < required %zu bytes", workspace_bytes, sgpo_mlp_workspace_bytes(m, B));
+    return SGPO_ERR_WORKSPACE;
+  }
+  hipStream_t st = (hipStream_t)stream;
+  float* hpre = (float*)workspace;
+  hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, st, mlp_dev(m), x, (const float*)nullptr, t, L, hpre,
+                     (float*)nullptr);
+  const int n_tiles = B * m->n_read;
+  int blocks = (n_tiles + 3) / 4;
+  if (blocks > 256 * 3) blocks = 256 * 3;  // 3 resident blocks per CU (LDS 49 KiB each), grid-stride the rest
+  float b5;
+  // b5 lives in device memory; it is added to both f and fbase and cancels in the ratio.
+  b5 = 0.f;
+  hipLaunchKernelGGL(mlp_jump_kernel, dim3(blocks), dim3(256), 0, st, m->w_perm, m->bias_perm, m->T1, m->read_pos, hpre, x,
+                     b5, n_tiles, m->n_read, m->alphabet, S, L, log_ratio);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}

@@ -1,0 +1,241 @@
+// Fused reverse-step kernels (HBM-bound): logits row -> parameterisation -> reverse
+// probabilities -> guidance reweighting -> categorical sample.  One vocabulary row per
+// 32-lane half-wave (K <= 32), lane k holds class k; all row reductions are half-wave
+// shuffles; logits are read once, coalesced, straight into registers.
+//
+// Reference algebra (bug-compatible forms):
+//   subs parameterisation  mdlm_diffusion.py:325-341
+//   MDLM.p_sample          models/mdlm.py:55-98
+//   CG reweight + sample   sampling/cls_guidance.py:38-52, models/mdlm.py:399-409
+//   _sample_categorical    mdlm_diffusion.py:69-73
+//   UDLM posterior         mdlm_diffusion.py:392-419
+//   q_xt                   mdlm_diffusion.py:585-597
+#include "../../include/sgpo_hip.h"
+#include "common.h"
+
+#define NEG_INF_REF (-1000000.0f)
+
+// index of the maximum inside a 32-lane half; ties -> lowest index (torch.argmax on CPU)
+__device__ __forceinline__ int half_argmax(float v, int k) {
+#pragma unroll
+  for (int o = 16; o > 0; o >>= 1) {
+    float ov = __shfl_xor(v, o);
+    int ok = __shfl_xor(k, o);
+    if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+  }
+  return k;
+}
+
+__device__ __forceinline__ float noise_denominator(int noise_mode, const float* noise, size_t local_idx,
+                                                   uint64_t seed, uint64_t offset, uint64_t global_idx, bool multinomial) {
+  // returns the value each probability is divided by before the argmax
+  if (noise_mode == SGPO_NOISE_EXPONENTIAL) return noise[local_idx];
+  float u;
+  if (noise_mode == SGPO_NOISE_UNIFORM) {
+    u = noise[local_idx];
+    if (multinomial) return -logf(1.0f - u);  // exponential from a uniform in [0,1)
+    return 1e-10f - logf(u + 1e-10f);
+  }
+  Philox4 r = philox4x32_10(seed, global_idx, offset);
+  u = u01_open(r.x);
+  if (multinomial) return -logf(u);
+  return 1e-10f - logf(u + 1e-10f);
+}
+
+__global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ x, const float* __restrict__ log_ratio,
+    const int* __restrict__ slot_of_pos, int n_slots, int rows, int L, int K, int mask_index, float mt, float ms,
+    float guide_temp, int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed,
+    uint64_t offset, uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out,
+    int* __restrict__ nan_flag) {
+  const int half = (blockIdx.x * 256 + threadIdx.x) >> 5;  // row index
+  const int k = threadIdx.x & 31;
+  if (half >= rows) return;
+  const int row = half;
+  const bool act = k < K;
+  const int xt = (int)x[row];
+  float z = act ? logits[(size_t)row * K + k] : -INFINITY;
+  // subs parameterisation
+  if (k == mask_index) z += NEG_INF_REF;
+  const float zmax = half_max(z);
+  const float se = half_sum(act ? expf(z - zmax) : 0.f);
+  float lp = z - (zmax + logf(se));  // logits - logsumexp
+  if (xt != mask_index) lp = (k == xt) ? 0.f : NEG_INF_REF;
+  float q = expf(lp) * (mt - ms);
+  if (k == mask_index) q = ms;
+  if (!act) q = 0.f;
+
+  if (step_mode == SGPO_STEP_SOFT) {
+    if (probs_out && act) probs_out[(size_t)row * K + k] = q;
+    return;
+  }
+  const size_t lidx = (size_t)row * K + k;
+  const uint64_t gidx = ((uint64_t)row + row_offset) * (uint64_t)K + k;
+  if (step_mode == SGPO_STEP_HARD) {
+    // _sample_categorical + carry-over (models/mdlm.py:81-84)
+    float den = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, false) : 1.f;
+    float v = act ? q / den : -INFINITY;
+    int samp = half_argmax(v, k);
+    if (probs_out && act) probs_out[lidx] = q;
+    if (k == 0) x_out[row] = (xt != mask_index) ? xt : samp;
+    return;
+  }
+  // classifier guidance (cls_guidance.py:38-52)
+  if (k == xt) q -= 1.0f;
+  if (log_ratio != nullptr && guide_temp != 0.f) {
+    const int l = row % L;
+    const int slot = slot_of_pos ? slot_of_pos[l] : l;
+    if (slot >= 0 && act) {
+      const int b = row / L;
+      float lr = log_ratio[((size_t)b * n_slots + slot) * K + k];
+      lr = lr / guide_temp;
+      if (lr == lr) lr = fminf(lr, 80.0f);  // torch.clamp propagates NaN, fminf would drop it
+      q = q * expf(lr);
+    }
+    if (nan_flag && act && q != q) *nan_flag = 1;
+  }
+  if (k == xt) q += 1.0f;
+  q = fmaxf(q, 0.f);
+  if (!act) q = 0.f;
+  const float tot = half_sum(q);
+  const float p = q / tot;
+  float den = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, true) : 1.f;
+  float v = act ? p / den : -INFINITY;
+  int samp = half_argmax(v, k);
+  if (probs_out && act) probs_out[lidx] = p;
+  if (k == 0) x_out[row] = samp;
+}
+
+extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* log_ratio,
+                                      const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
+                                      float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
+                                      int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                                      uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
+                                      void* stream) {
+  SGPO_REQUIRE(logits && x, "reverse_step_mdlm: null logits/x");
+  SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_mdlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
+  SGPO_REQUIRE(mask_index >= 0 && mask_index < K, "reverse_step_mdlm: mask_index %d outside [0,%d)", mask_index, K);
+  SGPO_REQUIRE(step_mode >= 0 && step_mode <= 2, "reverse_step_mdlm: bad step_mode %d", step_mode);
+  SGPO_REQUIRE(noise_mode >= 0 && noise_mode <= 2, "reverse_step_mdlm: bad noise_mode %d", noise_mode);
+  SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT || x_out, "reverse_step_mdlm: x_out required");
+  SGPO_REQUIRE(step_mode != SGPO_STEP_SOFT || probs_out, "reverse_step_mdlm: probs_out required for SOFT");
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_mdlm: noise tensor missing");
+  SGPO_REQUIRE(log_ratio == nullptr || slot_of_pos != nullptr || n_slots == L, "reverse_step_mdlm: n_slots must equal L without a slot map");
+  const int rows = B * L;
+  const int blocks = (rows + 7) / 8;
+  hipLaunchKernelGGL(reverse_step_mdlm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, x, log_ratio,
+                     slot_of_pos, n_slots, rows, L, K, mask_index, move_chance_t, move_chance_s, guide_temp, step_mode,
+                     noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// UDLM: log-softmax (d3pm parameterisation, no mask column) then _compute_posterior.
+__global__ __launch_bounds__(256) void reverse_step_udlm_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ x, int rows, int K, float mt, float ms,
+    int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed, uint64_t offset,
+    uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out) {
+  const int row = (blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int k = threadIdx.x & 31;
+  if (row >= rows) return;
+  const bool act = k < K;
+  const int xt = (int)x[row];
+  float z = act ? logits[(size_t)row * K + k] : -INFINITY;
+  const float zmax = half_max(z);
+  const float se = half_sum(act ? expf(z - zmax) : 0.f);
+  const float lp = z - (zmax + logf(se));
+  const float px = act ? expf(lp) : 0.f;  // x_theta
+  const float alpha_s = 1.f - ms, alpha_t = 1.f - mt;
+  const float alpha_ts = alpha_t / alpha_s;
+  const float d_alpha = alpha_s - alpha_t;
+  const float oh = (k == xt) ? 1.f : 0.f;
+  const float x_at_xt = __shfl(px, (threadIdx.x & 32) + xt);  // gather(x, -1, xt)
+  const float lim = 1.0f / (float)K;
+  const float num = alpha_t * (float)K * px * oh + (alpha_ts - alpha_t) * oh + d_alpha * px +
+                    (1.f - alpha_ts) * (1.f - alpha_s) * lim;
+  const float den = alpha_t * (float)K * x_at_xt + (1.f - alpha_t);
+  const float q = act ? num / den : 0.f;
+  const size_t lidx = (size_t)row * K + k;
+  if (probs_out && act) probs_out[lidx] = q;
+  if (step_mode == SGPO_STEP_SOFT) return;
+  const uint64_t gidx = ((uint64_t)row + row_offset) * (uint64_t)K + k;
+  float dn = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, false) : 1.f;
+  float v = act ? q / dn : -INFINITY;
+  int samp = half_argmax(v, k);
+  if (k == 0) x_out[row] = samp;
+}
+
+extern "C" int sgpo_reverse_step_udlm(const float* logits, const int64_t* x, int B, int L, int K,
+                                      float move_chance_t, float move_chance_s, int step_mode, int noise_mode,
+                                      const float* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
+                                      int64_t* x_out, float* probs_out, void* stream) {
+  SGPO_REQUIRE(logits && x, "reverse_step_udlm: null logits/x");
+  SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_udlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
+  SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT || step_mode == SGPO_STEP_HARD, "reverse_step_udlm: step_mode must be SOFT or HARD");
+  SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT ? probs_out != nullptr : x_out != nullptr, "reverse_step_udlm: output missing");
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_udlm: noise tensor missing");
+  const int rows = B * L;
+  hipLaunchKernelGGL(reverse_step_udlm_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, logits, x, rows,
+                     K, move_chance_t, move_chance_s, step_mode, noise_mode, noise, seed, offset, row_offset, x_out, probs_out);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void q_sample_mdlm_kernel(const int64_t* __restrict__ x, const float* __restrict__ mc,
+                                                            int rows, int L, int mask_index, int noise_mode,
+                                                            const float* __restrict__ noise, uint64_t seed, uint64_t offset,
+                                                            uint64_t row_offset, int64_t* __restrict__ x_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  float u;
+  if (noise_mode == SGPO_NOISE_PHILOX) {
+    Philox4 r = philox4x32_10(seed, (uint64_t)i + row_offset, offset);
+    u = (float)(r.x >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
+  } else {
+    u = noise[i];
+  }
+  x_out[i] = (u < mc[i / L]) ? (int64_t)mask_index : x[i];
+}
+
+extern "C" int sgpo_q_sample_mdlm(const int64_t* x, const float* move_chance, int B, int L, int mask_index,
+                                  int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                                  uint64_t row_offset, int64_t* x_out, void* stream) {
+  SGPO_REQUIRE(x && move_chance && x_out, "q_sample_mdlm: null argument");
+  SGPO_REQUIRE(B > 0 && L > 0, "q_sample_mdlm: B=%d L=%d", B, L);
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || (noise_mode == SGPO_NOISE_UNIFORM && noise), "q_sample_mdlm: noise_mode must be 0 or 2 (+tensor)");
+  const int rows = B * L;
+  hipLaunchKernelGGL(q_sample_mdlm_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, move_chance,
+                     rows, L, mask_index, noise_mode, noise, seed, offset, row_offset, x_out);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void categorical_kernel(const float* __restrict__ probs, int64_t rows, int K,
+                                                          int noise_mode, const float* __restrict__ noise, uint64_t seed,
+                                                          uint64_t offset, uint64_t row_offset, int64_t* __restrict__ out) {
+  const int64_t row = ((int64_t)blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int k = threadIdx.x & 31;
+  if (row >= rows) return;
+  const bool act = k < K;
+  const size_t lidx = (size_t)row * K + k;
+  const float p = act ? probs[lidx] : 0.f;
+  const uint64_t gidx = ((uint64_t)row + row_offset) * (uint64_t)K + k;
+  float den = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, noise_mode != SGPO_NOISE_UNIFORM) : 1.f;
+  float v = act ? p / den : -INFINITY;
+  int samp = half_argmax(v, k);
+  if (k == 0) out[row] = samp;
+}
+
+extern "C" int sgpo_categorical_sample(const float* probs, int64_t rows, int K, int noise_mode, const float* noise,
+                                       uint64_t seed, uint64_t offset, uint64_t row_offset, int64_t* out, void* stream) {
+  SGPO_REQUIRE(probs && out, "categorical_sample: null argument");
+  SGPO_REQUIRE(rows > 0 && K > 0 && K <= 32, "categorical_sample: rows=%lld K=%d (K <= 32)", (long long)rows, K);
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise, "categorical_sample: noise tensor missing");
+  hipLaunchKernelGGL(categorical_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, probs, rows,
+                     K, noise_mode, noise, seed, offset, row_offset, out);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}

@@ -1,0 +1,263 @@
+"""Thin torch-side owners of the library handles and workspaces.
+
+PyTorch is plumbing here (device memory, the current HIP stream); every
+computation below is a call into libsgpo_hip.so.
+"""
+import ctypes as C
+import itertools
+
+import torch
+
+from . import _lib as L
+from . import weights as W
+
+_initialised = set()
+
+
+def init(device=None):
+    """Bind this process to a GPU (one rank per GPU) and load the library."""
+    lib = L.load()
+    if not torch.cuda.is_available():
+        raise L.SgpoError('no GPU visible: the SGPO hot path runs on MI355X only (no CPU fallback)')
+    dev = torch.device(device if device is not None else 'cuda')
+    idx = dev.index if dev.index is not None else torch.cuda.current_device()
+    if idx not in _initialised:
+        torch.cuda.set_device(idx)
+        L.check(lib.sgpo_init(idx), 'sgpo_init')
+        _initialised.add(idx)
+    return torch.device('cuda', idx)
+
+
+DIT_ORDER_HEAD = ['vocab_embed.embedding', 'sigma_map.mlp.0.weight', 'sigma_map.mlp.0.bias',
+                  'sigma_map.mlp.2.weight', 'sigma_map.mlp.2.bias']
+DIT_ORDER_BLOCK = ['norm1.weight', 'attn_qkv.weight', 'attn_out.weight', 'norm2.weight', 'mlp.0.weight',
+                   'mlp.0.bias', 'mlp.2.weight', 'mlp.2.bias', 'adaLN_modulation.weight', 'adaLN_modulation.bias']
+DIT_ORDER_TAIL = ['output_layer.norm_final.weight', 'output_layer.linear.weight', 'output_layer.linear.bias',
+                  'output_layer.adaLN_modulation.weight', 'output_layer.adaLN_modulation.bias']
+MLP_ORDER = ['time_embedder.0.W', 'time_embedder.1.weight', 'time_embedder.1.bias', 'embedder.weight',
+             'embedder.bias', 'mlp.0.weight', 'mlp.0.bias', 'mlp.2.weight', 'mlp.2.bias', 'mlp.4.weight',
+             'mlp.4.bias', 'cls_head.0.weight', 'cls_head.0.bias', 'cls_head.2.weight', 'cls_head.2.bias']
+
+
+def _blob(sd, keys, device):
+    return torch.cat([sd[k].detach().to(torch.float32).reshape(-1) for k in keys]).to(device).contiguous()
+
+
+class Workspace:
+    """Grow-only device scratch buffer owned by the caller side (torch allocator)."""
+
+    def __init__(self, device):
+        self.device = device
+        self.buf = None
+
+    def get(self, nbytes):
+        if self.buf is None or self.buf.numel() < nbytes:
+            self.buf = torch.empty(int(nbytes) + 256, dtype=torch.uint8, device=self.device)
+        return self.buf
+
+
+class DitDenoiser:
+    """DIT.forward on the GPU (dit.py:375-418) from a reference-keyed state dict."""
+
+    def __init__(self, state_dict, device=None, max_len=1024):
+        self.device = init(device)
+        self.lib = L.load()
+        d = W.dit_dims(state_dict)
+        self.dims = d
+        self.vocab, self.hidden = d['vocab'], d['hidden']
+        self.cfg = L.DitConfig(d['vocab'], d['hidden'], d['cond_dim'], d['freq_dim'], d['n_blocks'], d['n_heads'],
+                               d['mlp_hidden'], max_len)
+        keys = DIT_ORDER_HEAD + [f'blocks.{i}.{k}' for i in range(d['n_blocks']) for k in DIT_ORDER_BLOCK] + DIT_ORDER_TAIL
+        blob = _blob(state_dict, keys, self.device)
+        n = self.lib.sgpo_dit_param_count(C.byref(self.cfg))
+        if blob.numel() != n:
+            raise L.SgpoError(f'DiT state dict has {blob.numel()} parameters, library expects {n}')
+        h = C.c_void_p()
+        L.check(self.lib.sgpo_dit_create(C.byref(self.cfg), L.ptr(blob), blob.numel(), C.byref(h)), 'sgpo_dit_create')
+        self.handle = h
+        self.ws = Workspace(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.sgpo_dit_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, tokens, sigma=None, x_emb=None, return_hidden=False, out=None):
+        """tokens (B,L) int64; sigma None (=0), (1,) or (B,) fp32 -> logits (B,L,V) fp32."""
+        B, Lq = tokens.shape
+        tokens = tokens.contiguous()
+        assert tokens.dtype == torch.int64 and tokens.is_cuda
+        need = self.lib.sgpo_dit_workspace_bytes(self.handle, B, Lq)
+        ws = self.ws.get(need)
+        base = (ws.data_ptr() + 255) & ~255
+        logits = out if out is not None else torch.empty(B, Lq, self.vocab, dtype=torch.float32, device=self.device)
+        hidden = torch.empty(B, Lq, self.hidden, dtype=torch.float32, device=self.device) if return_hidden else None
+        if sigma is not None:
+            sigma = sigma.to(self.device, torch.float32).reshape(-1).contiguous()
+        if x_emb is not None:
+            x_emb = x_emb.to(self.device, torch.float32).contiguous()
+        L.check(self.lib.sgpo_dit_forward(self.handle, L.ptr(tokens), L.ptr(sigma),
+                                          0 if sigma is None else sigma.numel(), B, Lq, L.ptr(x_emb), L.ptr(logits),
+                                          L.ptr(hidden), C.c_void_p(base), need, L.stream_ptr()), 'sgpo_dit_forward')
+        return (logits, hidden) if return_hidden else logits
+
+
+class MlpValueFunction:
+    """MLPModel (problem/protein.py:58-121) on the GPU, incl. the factored jump-ratio kernel."""
+
+    def __init__(self, state_dict, read_pos, alphabet=31, hidden=64, time_conditioned=True, device=None):
+        self.device = init(device)
+        self.lib = L.load()
+        self.read_pos = [int(p) for p in read_pos]
+        self.n_read = len(self.read_pos)
+        self.alphabet = alphabet
+        blob = _blob(state_dict, MLP_ORDER, self.device)
+        arr = (C.c_int * self.n_read)(*self.read_pos)
+        h = C.c_void_p()
+        L.check(self.lib.sgpo_mlp_create(L.ptr(blob), blob.numel(), self.n_read, arr, alphabet, hidden,
+                                         1 if time_conditioned else 0, C.byref(h)), 'sgpo_mlp_create')
+        self.handle = h
+        self.ws = Workspace(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.sgpo_mlp_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, x, t=None):
+        B, Lq = x.shape
+        x = x.contiguous()
+        if max(self.read_pos) >= Lq:
+            raise L.SgpoError(f'value function reads position {max(self.read_pos)} of a length-{Lq} sequence')
+        out = torch.empty(B, dtype=torch.float32, device=self.device)
+        if t is not None:
+            t = t.to(self.device, torch.float32).reshape(-1).contiguous()
+            assert t.numel() == B
+        L.check(self.lib.sgpo_mlp_forward(self.handle, L.ptr(x), L.ptr(t), B, Lq, L.ptr(out), L.stream_ptr()),
+                'sgpo_mlp_forward')
+        return out
+
+    def jump_log_ratios(self, x, t, S, out=None):
+        """log_ratio (B, n_read, S) = f(x with x[read_pos[i]] <- s, t) - f(x, t)."""
+        B, Lq = x.shape
+        x = x.contiguous()
+        if max(self.read_pos) >= Lq:
+            raise L.SgpoError(f'value function reads position {max(self.read_pos)} of a length-{Lq} sequence')
+        need = self.lib.sgpo_mlp_workspace_bytes(self.handle, B)
+        ws = self.ws.get(need)
+        base = (ws.data_ptr() + 255) & ~255
+        if out is None:
+            out = torch.empty(B, self.n_read, S, dtype=torch.float32, device=self.device)
+        L.check(self.lib.sgpo_guidance_ratio_mlp(self.handle, L.ptr(x), float(t), B, Lq, S, L.ptr(out),
+                                                 C.c_void_p(base), need, L.stream_ptr()), 'sgpo_guidance_ratio_mlp')
+        return out
+
+
+class NoiseSource:
+    """Counter-based noise bookkeeping: one (seed, call offset) pair per sampling kernel call.
+
+    Philox counters are keyed by the GLOBAL row index (row_offset = first row of this rank's
+    shard), so a batch sharded over ranks draws the same numbers as the unsharded batch.
+    """
+
+    def __init__(self, seed=42, row_offset=0):
+        self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+        self.row_offset = int(row_offset)
+        self._calls = itertools.count()
+
+    def next_offset(self):
+        return next(self._calls)
+
+
+def reverse_step_mdlm(logits, x, mt, ms, mask_index, step_mode, noise_src=None, noise=None, noise_mode=None,
+                      log_ratio=None, slot_of_pos=None, guide_temp=0.0, want_probs=False, nan_flag=None, x_out=None,
+                      L_seq=None):
+    lib = L.load()
+    B, Lq, K = logits.shape
+    x = x.contiguous()
+    logits = logits.contiguous()
+    if noise is not None:
+        noise = noise.contiguous()
+        assert noise.dtype == torch.float32
+        if noise_mode is None:
+            noise_mode = L.NOISE_EXPONENTIAL if step_mode == L.STEP_SOFT_CG else L.NOISE_UNIFORM
+    else:
+        noise_mode = L.NOISE_PHILOX
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    probs = torch.empty_like(logits) if (want_probs or step_mode == L.STEP_SOFT) else None
+    if step_mode != L.STEP_SOFT and x_out is None:
+        x_out = torch.empty_like(x)
+    n_slots = Lq if log_ratio is None else log_ratio.shape[1]
+    L.check(lib.sgpo_reverse_step_mdlm(L.ptr(logits), L.ptr(x), L.ptr(log_ratio), L.ptr(slot_of_pos), n_slots, B, Lq, K,
+                                       mask_index, float(mt), float(ms), float(guide_temp), step_mode, noise_mode,
+                                       L.ptr(noise), seed, off, row_off * Lq, L.ptr(x_out), L.ptr(probs),
+                                       L.ptr(nan_flag), L.stream_ptr()), 'sgpo_reverse_step_mdlm')
+    return x_out, probs
+
+
+def reverse_step_udlm(logits, x, mt, ms, step_mode, noise_src=None, noise=None, want_probs=False):
+    lib = L.load()
+    B, Lq, K = logits.shape
+    x = x.contiguous()
+    logits = logits.contiguous()
+    noise_mode = L.NOISE_PHILOX if noise is None else L.NOISE_UNIFORM
+    if noise is not None:
+        noise = noise.contiguous()
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    probs = torch.empty_like(logits) if (want_probs or step_mode == L.STEP_SOFT) else None
+    x_out = torch.empty_like(x) if step_mode != L.STEP_SOFT else None
+    L.check(lib.sgpo_reverse_step_udlm(L.ptr(logits), L.ptr(x), B, Lq, K, float(mt), float(ms), step_mode, noise_mode,
+                                       L.ptr(noise), seed, off, row_off * Lq, L.ptr(x_out), L.ptr(probs),
+                                       L.stream_ptr()), 'sgpo_reverse_step_udlm')
+    return x_out, probs
+
+
+def q_sample_mdlm(x, move_chance, mask_index, noise_src=None, noise=None):
+    lib = L.load()
+    B, Lq = x.shape
+    x = x.contiguous()
+    move_chance = move_chance.to(x.device, torch.float32).reshape(-1).contiguous()
+    assert move_chance.numel() == B
+    noise_mode = L.NOISE_PHILOX if noise is None else L.NOISE_UNIFORM
+    if noise is not None:
+        noise = noise.contiguous()
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    out = torch.empty_like(x)
+    L.check(lib.sgpo_q_sample_mdlm(L.ptr(x), L.ptr(move_chance), B, Lq, mask_index, noise_mode, L.ptr(noise), seed, off,
+                                   row_off * Lq, L.ptr(out), L.stream_ptr()), 'sgpo_q_sample_mdlm')
+    return out
+
+
+def categorical_sample(probs, noise_src=None, noise=None, noise_mode=None):
+    lib = L.load()
+    K = probs.shape[-1]
+    rows = probs.numel() // K
+    probs = probs.to(torch.float32).contiguous()
+    if noise is not None:
+        noise = noise.to(torch.float32).contiguous()
+        noise_mode = L.NOISE_EXPONENTIAL if noise_mode is None else noise_mode
+    else:
+        noise_mode = L.NOISE_PHILOX
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    out = torch.empty(probs.shape[:-1], dtype=torch.int64, device=probs.device)
+    L.check(lib.sgpo_categorical_sample(L.ptr(probs), rows, K, noise_mode, L.ptr(noise), seed, off, row_off,
+                                        L.ptr(out), L.stream_ptr()), 'sgpo_categorical_sample')
+    return out
+
+
+def gemm_bf16(a, w):
+    """Test access: a (M,K) fp32/bf16, w (N,K) -> (M,N) fp32 via the MFMA kernel."""
+    lib = L.load()
+    a16 = a.to(torch.bfloat16).contiguous()
+    w16 = w.to(torch.bfloat16).contiguous()
+    M, K = a16.shape
+    N = w16.shape[0]
+    out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    L.check(lib.sgpo_gemm_bf16(L.ptr(a16), L.ptr(w16), L.ptr(out), M, N, K, L.stream_ptr()), 'sgpo_gemm_bf16')
+    return out
