@@ -1,0 +1,209 @@
+"""Benchmark of the SGPO guided-sampling hot path on MI355X.
+
+Workload (BASELINE.json configs[1]): MDLM (DiT h512 / 8 blocks / 8 heads / cond 128 / K 31)
++ cls_guidance_discrete (exact guidance, temperature 0.064, MLP value function hidden 64) on
+CreiLOV (L = 119), batch 4096 per GPU, 127 reverse steps.  One bench "step" = one full
+`Classifier_Guidance_Inpaint.inference(num_samples=4096)` = 4096 guided sequences per GPU.
+Weights are seeded synthetic (no checkpoints offline), tokens start fully masked, noise is
+in-kernel Philox.  With N GPUs every rank samples its own 4096-sequence shard (weak scaling,
+Philox counters offset by the global row) and the ranks all-gather tokens (uint8) + value
+function scores over RCCL, as SURVEY.md section 8(e) lays out.
+
+    python bench.py --gpus 1 --steps 2 --warmup 1
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch
+stream during the timed steps) and `cpu_baseline` (the CPU oracle on a bounded sample).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CREILOV = ('MAGLRHTFVVADATLPDCPLVYASEGFYAMTGYGPDEVLGHNARFLQGEGTDPKEVQKIRDAIKKGEACSVRLLNYRKDGTPFWNLL'
+           'TVTPIKTPDGRVSKFVGVQVDVTSKTEGKALA')
+ALPHABET = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+T_STEPS = 128
+TEMPERATURE = 0.064
+MFMA_BF16_PEAK_TFLOPS = 2500.0   # MI355X dense bf16 (MI355X_MICROARCH.md)
+HBM_PEAK_GBS = 8000.0
+
+
+def build(device, batch, dit_seed=0, mlp_seed=1):
+    import sgpo_amd
+    sgpo_amd.install_dropin()
+    from models.mdlm import MDLM
+    from problem.protein import ProteinPredictor
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    from sgpo_amd import weights as W
+    cfg = dict(diffusion='absorbing_state', parameterization='subs', time_conditioning=False,
+               model=dict(hidden_size=512, cond_dim=128, n_blocks=8, n_heads=8, length=1024))
+    sd = W.dit_synthetic_state(seed=dit_seed)
+    net = MDLM('synthetic', cfg, None, num_steps=T_STEPS, seq_len=119, device=device, state_dict=sd)
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=119, full_seq=CREILOV, residues=None)
+    pred = ProteinPredictor(dc, dict(hidden_dim=64), device=device)
+    msd = W.mlp_synthetic_state(seed=mlp_seed, n_residues=119)
+    pred.model.load_state_dict(msd)
+    pred.eval()
+    algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred, temperature=TEMPERATURE, device=device)
+    return net, pred, algo, sd, msd
+
+
+def cpu_baseline(sd, msd, n_seq=4, n_steps=16):
+    """The CPU oracle (reference formulation incl. materialised jumps) on a bounded sample:
+    n_seq sequences x the first n_steps of the 127 reverse steps, scaled to whole sequences."""
+    from oracle import cls_guidance as ocg
+    from oracle import mdlm as omdlm
+    from oracle import mlp as omlp
+    cores = min(os.cpu_count() or 1, 16)
+    torch.set_num_threads(cores)
+    pred = omlp.Predictor(msd)
+    gen = torch.Generator().manual_seed(1234)
+    x = 28 * torch.ones((n_seq, 119), dtype=torch.int64)
+    ts = torch.linspace(T_STEPS - 1, 1, T_STEPS - 1, dtype=int)[:n_steps]
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for t in ts:
+            q = omdlm.p_sample(sd, x, t, T_STEPS, 28, hard=False)
+            e = torch.empty(n_seq, 119, 31).exponential_(1, generator=gen)
+            xx = x
+            x, _ = ocg.cg_step(q, x, lambda qm: omdlm.get_guided_rates(pred, xx, t, qm, 31, TEMPERATURE)[0], e)
+    dt = time.perf_counter() - t0
+    per_seq = dt / n_seq * (T_STEPS - 1) / n_steps
+    return dict(value=1.0 / per_seq, unit='sequences/s', cores=cores, kind='port',
+                sample=f'{n_seq} sequences x {n_steps} of 127 guided steps (B={n_seq}), torch-CPU fp32 oracle, '
+                       f'{dt:.1f} s measured, scaled linearly to 127 steps')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=2)
+    ap.add_argument('--warmup', type=int, default=1)
+    ap.add_argument('--batch', type=int, default=4096, help='sequences per GPU per step')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-prof', action='store_true')
+    a = ap.parse_args()
+
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != a.gpus:
+        if world == 1 and a.gpus > 1:
+            raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    dist = None
+    device = f'cuda:{local_rank}'
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device(device))
+
+    from sgpo_amd import _lib as L
+    net, pred, algo, sd, msd = build(device, a.batch)
+    lib = L.load()
+    B = a.batch
+
+    def one_step(step_idx):
+        # shard-invariant noise: global row offset of this rank's shard; new key per step
+        net.reseed(seed=42 + step_idx, row_offset=rank * B)
+        x = algo.inference(num_samples=B)
+        score = pred.log_likelihood(x)
+        if world > 1:
+            toks = x.to(torch.uint8)
+            all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
+            all_s = torch.empty(world * B, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(all_t, toks)
+            dist.all_gather_into_tensor(all_s, score)
+            return all_t, all_s
+        return x, score
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(-1 - i)
+    sync()
+    n_launch = a.steps * (T_STEPS - 1) * 80 + 64
+    if not a.no_prof:
+        L.check(lib.sgpo_prof_enable(1, n_launch), 'prof_enable')
+    t0 = time.perf_counter()
+    out = None
+    for i in range(a.steps):
+        out = one_step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    roof = None
+    kernels = {}
+    if not a.no_prof:
+        n = L.PROF_KINDS
+        ms = (C.c_double * n)()
+        cnt = (C.c_int64 * n)()
+        work = (C.c_double * n)()
+        L.check(lib.sgpo_prof_read(n, ms, cnt, work), 'prof_read')
+        lib.sgpo_prof_enable(0, 0)
+        tot = sum(ms)
+        for k in range(n):
+            if cnt[k]:
+                kernels[lib.sgpo_prof_kind_name(k).decode()] = dict(
+                    total_ms=round(ms[k], 3), launches=int(cnt[k]), avg_us=round(1e3 * ms[k] / cnt[k], 2),
+                    share=round(ms[k] / tot, 4), work_per_launch=work[k] / cnt[k])
+        dom = max(range(n), key=lambda k: ms[k])
+        name = lib.sgpo_prof_kind_name(dom).decode()
+        is_mfma = name.startswith('gemm') or name.startswith('attention') or name.startswith('mlp_jump')
+        per_launch = work[dom] / cnt[dom]
+        avg_s = ms[dom] / cnt[dom] * 1e-3
+        if is_mfma:
+            ach = per_launch / avg_s / 1e12
+            roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None,
+                        avg_launch_us=round(avg_s * 1e6, 2), flops_per_launch=per_launch)
+        else:
+            ach = per_launch / avg_s / 1e9
+            roof = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(avg_s * 1e6, 2),
+                        bytes_per_launch=per_launch)
+        # whole-denoiser MFMA utilisation (all GEMM + attention flops over their summed time)
+        gf = sum(work[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
+        gt = sum(ms[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
+        if gt > 0:
+            roof['denoiser_tflops'] = round(gf / (gt * 1e-3) / 1e12, 2)
+            roof['gpu_busy_frac'] = round(tot * 1e-3 / dt, 4)
+
+    if rank == 0:
+        cpu = None
+        if not a.no_cpu_baseline:
+            cpu = cpu_baseline(sd, msd)
+        total_seq = world * B * a.steps
+        line = {
+            'metric': 'guided sequences/sec (whole node)', 'value': round(total_seq / dt, 2), 'unit': 'sequences/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic',
+            'config': {'workload': 'MDLM + cls_guidance_discrete (exact guidance, temperature 0.064) on CreiLOV, '
+                                   'L=119, K=31, 127 reverse steps, batch %d per GPU' % B,
+                       'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate',
+                       'value_function': 'MLPModel hidden 64, fp32', 'global_batch': world * B,
+                       'parallelism': f'dp{world} (independent shards + all-gather of tokens/scores)'},
+            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
+        }
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

@@ -35,6 +35,7 @@ extern "C" {
 #define SGPO_NOISE_PHILOX 0
 #define SGPO_NOISE_EXPONENTIAL 1 /* noise = Exp(1) draws e; sample = argmax(p / e)  (torch.multinomial) */
 #define SGPO_NOISE_UNIFORM 2     /* noise = U[0,1) draws u; sample = argmax(p / (1e-10 - log(u + 1e-10))) */
+#define SGPO_NOISE_NONE 3        /* no noise: plain argmax (the "noise removal" step, mdlm_diffusion.py:692-699) */
 
 #define SGPO_STEP_SOFT 0    /* write q (unnormalised soft reverse probabilities), no sampling */
 #define SGPO_STEP_SOFT_CG 1 /* classifier-guidance step: reweight, normalise, multinomial */
@@ -136,6 +137,17 @@ int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L
 /* C[M][N] (fp32) = A[M][K] (bf16) * W[N][K]^T (bf16) through the MFMA GEMM kernel. */
 int sgpo_gemm_bf16(const void* A, const void* W, float* C, int M, int N, int K, void* stream);
 int sgpo_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
+
+/* ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) -----
+ * No counterpart in the reference (it has no profiling).  enable(1, n)
+ * preallocates events for n launches; read() synchronises and returns, per kernel kind,
+ * total milliseconds, launch count and total algorithmic work (flops for MFMA kernels,
+ * bytes for HBM-bound kernels).  SGPO_PROF_KINDS slots are required. */
+#define SGPO_PROF_KINDS 17
+int sgpo_prof_enable(int on, int max_launches);
+int sgpo_prof_reset(void);
+int sgpo_prof_read(int n_kinds, double* total_ms, int64_t* launches, double* work);
+const char* sgpo_prof_kind_name(int kind);
 
 #ifdef __cplusplus
 }

@@ -9,8 +9,9 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsgpo_hip.so')
 
-NOISE_PHILOX, NOISE_EXPONENTIAL, NOISE_UNIFORM = 0, 1, 2
+NOISE_PHILOX, NOISE_EXPONENTIAL, NOISE_UNIFORM, NOISE_NONE = 0, 1, 2, 3
 STEP_SOFT, STEP_SOFT_CG, STEP_HARD = 0, 1, 2
+PROF_KINDS = 17
 
 
 class SgpoError(RuntimeError):
@@ -46,6 +47,10 @@ SIGNATURES = {
     'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sgpo_gemm_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'sgpo_f32_to_bf16': (_i, [_vp, _vp, _sz, _vp]),
+    'sgpo_prof_enable': (_i, [_i, _i]),
+    'sgpo_prof_reset': (_i, []),
+    'sgpo_prof_read': (_i, [_i, C.POINTER(C.c_double), C.POINTER(C.c_int64), C.POINTER(C.c_double)]),
+    'sgpo_prof_kind_name': (C.c_char_p, [_i]),
 }
 
 _lib = None

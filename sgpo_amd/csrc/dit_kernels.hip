@@ -3,6 +3,7 @@
 // Reference: models/pretraining/model/mdlm/models/dit.py (line refs per kernel).
 #include "common.h"
 #include "dit.h"
+#include "prof.h"
 
 // ---------------------------------------------------------------------------
 // RoPE tables  cos/sin[pos][i], i < head_dim/2   (dit.py:81-104: inv_freq = 1/10000^(2i/d))
@@ -158,6 +159,7 @@ __global__ __launch_bounds__(256) void ln_mod_generic_kernel(const float* __rest
 int launch_ln_mod(const float* x, const float* w, const float* shift, const float* scale, int mod_stride,
                   bf16_t* out, int M, int L, int B, int H, hipStream_t stream) {
   dim3 grid((M + 3) / 4), block(256);
+  ProfScope prof_scope(PK_LN_MOD, stream, (double)M * H * 6.0);  // 4H read + 2H written
   if (H == 512 && shift && scale)
     hipLaunchKernelGGL(ln_mod_kernel<512>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B);
   else if (H == 1024 && shift && scale)
@@ -312,12 +314,14 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
     attr_lds = lds;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
+  ProfScope prof_scope(PK_ATTENTION, stream, 4.0 * B * n_heads * (double)L * L * head_dim);
   hipLaunchKernelGGL(attention_kernel, dim3(B * n_heads), dim3(256), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
 
 int launch_embed(const int64_t* tok, const float* emb, float* x, int M, int H, int vocab, hipStream_t stream) {
+  ProfScope prof_scope(PK_EMBED, stream, (double)M * H * 8.0);
   hipLaunchKernelGGL(embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tok, emb, x, M, H, vocab);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;

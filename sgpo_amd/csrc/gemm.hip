@@ -1,5 +1,6 @@
 // bf16 MFMA GEMM with fused epilogues -- see gemm.h for the design notes.
 #include "gemm.h"
+#include "prof.h"
 
 #define BM 128
 #define BN 128
@@ -227,6 +228,7 @@ int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, con
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn), block(256);
   const size_t lds = 4 * TILE_BYTES;
+  ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
 #define LAUNCH(E)                                                                                   \
   case E: {                                                                                         \
     static bool attr_set = false;                                                                   \

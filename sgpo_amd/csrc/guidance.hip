@@ -15,6 +15,7 @@
 
 #include "../../include/sgpo_hip.h"
 #include "common.h"
+#include "prof.h"
 
 #define MH 64  // hidden width (problem/protein.py: hidden_dim 64)
 
@@ -311,14 +312,19 @@ extern "C" int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, i
   }
   hipStream_t st = (hipStream_t)stream;
   float* hpre = (float*)workspace;
-  hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, st, mlp_dev(m), x, (const float*)nullptr, t, L, hpre,
-                     (float*)nullptr);
+  {
+    ProfScope prof_scope(PK_MLP_BASE, st, (double)B * m->n_read * MH * 4.0);
+    hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, st, mlp_dev(m), x, (const float*)nullptr, t, L, hpre,
+                       (float*)nullptr);
+  }
   const int n_tiles = B * m->n_read;
   int blocks = (n_tiles + 3) / 4;
   if (blocks > 256 * 3) blocks = 256 * 3;  // 3 resident blocks per CU (LDS 49 KiB each), grid-stride the rest
   float b5;
   // b5 lives in device memory; it is added to both f and fbase and cancels in the ratio.
   b5 = 0.f;
+  // factored jump cost: three 64x64 layers + first-layer update + head per (b, i, s)
+  ProfScope prof_scope(PK_MLP_JUMP, st, (double)n_tiles * S * (3.0 * 2 * MH * MH + 5.0 * MH));
   hipLaunchKernelGGL(mlp_jump_kernel, dim3(blocks), dim3(256), 0, st, m->w_perm, m->bias_perm, m->T1, m->read_pos, hpre, x,
                      b5, n_tiles, m->n_read, m->alphabet, S, L, log_ratio);
   SGPO_CHECK_HIP(hipGetLastError());

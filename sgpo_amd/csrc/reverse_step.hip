@@ -12,6 +12,7 @@
 //   q_xt                   mdlm_diffusion.py:585-597
 #include "../../include/sgpo_hip.h"
 #include "common.h"
+#include "prof.h"
 
 #define NEG_INF_REF (-1000000.0f)
 
@@ -29,6 +30,7 @@ __device__ __forceinline__ int half_argmax(float v, int k) {
 __device__ __forceinline__ float noise_denominator(int noise_mode, const float* noise, size_t local_idx,
                                                    uint64_t seed, uint64_t offset, uint64_t global_idx, bool multinomial) {
   // returns the value each probability is divided by before the argmax
+  if (noise_mode == SGPO_NOISE_NONE) return 1.0f;
   if (noise_mode == SGPO_NOISE_EXPONENTIAL) return noise[local_idx];
   float u;
   if (noise_mode == SGPO_NOISE_UNIFORM) {
@@ -116,13 +118,16 @@ extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, con
   SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_mdlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
   SGPO_REQUIRE(mask_index >= 0 && mask_index < K, "reverse_step_mdlm: mask_index %d outside [0,%d)", mask_index, K);
   SGPO_REQUIRE(step_mode >= 0 && step_mode <= 2, "reverse_step_mdlm: bad step_mode %d", step_mode);
-  SGPO_REQUIRE(noise_mode >= 0 && noise_mode <= 2, "reverse_step_mdlm: bad noise_mode %d", noise_mode);
+  SGPO_REQUIRE(noise_mode >= 0 && noise_mode <= 3, "reverse_step_mdlm: bad noise_mode %d", noise_mode);
   SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT || x_out, "reverse_step_mdlm: x_out required");
   SGPO_REQUIRE(step_mode != SGPO_STEP_SOFT || probs_out, "reverse_step_mdlm: probs_out required for SOFT");
-  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_mdlm: noise tensor missing");
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise_mode == SGPO_NOISE_NONE || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_mdlm: noise tensor missing");
   SGPO_REQUIRE(log_ratio == nullptr || slot_of_pos != nullptr || n_slots == L, "reverse_step_mdlm: n_slots must equal L without a slot map");
   const int rows = B * L;
   const int blocks = (rows + 7) / 8;
+  // algorithmic bytes: logits + x in, x out (+ ratio for guided steps)
+  ProfScope prof_scope(PK_REVERSE_STEP, (hipStream_t)stream,
+                       (double)rows * (K * 4.0 * ((log_ratio && guide_temp != 0.f && step_mode == SGPO_STEP_SOFT_CG) ? 2 : 1) + 16.0));
   hipLaunchKernelGGL(reverse_step_mdlm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, x, log_ratio,
                      slot_of_pos, n_slots, rows, L, K, mask_index, move_chance_t, move_chance_s, guide_temp, step_mode,
                      noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag);
@@ -174,7 +179,7 @@ extern "C" int sgpo_reverse_step_udlm(const float* logits, const int64_t* x, int
   SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_udlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
   SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT || step_mode == SGPO_STEP_HARD, "reverse_step_udlm: step_mode must be SOFT or HARD");
   SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT ? probs_out != nullptr : x_out != nullptr, "reverse_step_udlm: output missing");
-  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_udlm: noise tensor missing");
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise_mode == SGPO_NOISE_NONE || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_udlm: noise tensor missing");
   const int rows = B * L;
   hipLaunchKernelGGL(reverse_step_udlm_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, logits, x, rows,
                      K, move_chance_t, move_chance_s, step_mode, noise_mode, noise, seed, offset, row_offset, x_out, probs_out);
@@ -233,7 +238,7 @@ extern "C" int sgpo_categorical_sample(const float* probs, int64_t rows, int K, 
                                        uint64_t seed, uint64_t offset, uint64_t row_offset, int64_t* out, void* stream) {
   SGPO_REQUIRE(probs && out, "categorical_sample: null argument");
   SGPO_REQUIRE(rows > 0 && K > 0 && K <= 32, "categorical_sample: rows=%lld K=%d (K <= 32)", (long long)rows, K);
-  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise, "categorical_sample: noise tensor missing");
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise_mode == SGPO_NOISE_NONE || noise, "categorical_sample: noise tensor missing");
   hipLaunchKernelGGL(categorical_kernel, dim3((unsigned)((rows + 7) / 8)), dim3(256), 0, (hipStream_t)stream, probs, rows,
                      K, noise_mode, noise, seed, offset, row_offset, out);
   SGPO_CHECK_HIP(hipGetLastError());

@@ -1,0 +1,287 @@
+"""Drop-in `models.mdlm.MDLM` (reference: models/mdlm.py:22-413) on the HIP library.
+
+Same constructor and method signatures as the reference wrapper; every tensor
+computation is a call into libsgpo_hip.so (sgpo_amd.runtime).  Defects of the
+reference that shape results are reproduced by default:
+  D1  `_sample_categorical` is the one of mdlm_diffusion.py:69-73
+  D2  `t_next = t / T` re-divides the scaled t (models/mdlm.py:57-58); set
+      `t_next_mode='corrected'` for the intended `(t-1)/T`
+  D6  dropout is off (eval mode)
+"""
+import math
+import os
+from collections import deque
+
+import torch
+
+from sgpo_amd import _lib as L
+from sgpo_amd import runtime as rt
+from sgpo_amd import weights as W
+from sgpo_amd.tokenizer import Tokenizer
+
+from .base import GenerativeModel, cfg_get
+
+EPS = 1e-3
+
+
+class LogLinearNoise:
+    """noise_schedule.py:126-144; returns (total_noise, rate_noise)."""
+
+    def __init__(self, eps=EPS):
+        self.eps = eps
+
+    def __call__(self, t):
+        t = torch.as_tensor(t, dtype=torch.float32)
+        return -torch.log1p(-(1 - self.eps) * t), (1 - self.eps) / (1 - (1 - self.eps) * t)
+
+
+class _Core:
+    """Stands where the reference keeps its `MDLMDiffusion` (`net.model`): the attributes
+    callers read (models/mdlm.py:36,53,59; pareto.py:95)."""
+
+    def __init__(self, backbone, state_dict, config, tokenizer):
+        self.backbone = backbone
+        self._state_dict = state_dict
+        self.config = config
+        self.tokenizer = tokenizer
+        self.vocab_size = len(tokenizer.alphabet)
+        self.mask_index = tokenizer.mask_id
+        self.noise = LogLinearNoise()
+        self.neg_infinity = -1000000.0
+        self.time_conditioning = bool(cfg_get(config, 'time_conditioning', False))
+        self.parameterization = cfg_get(config, 'parameterization', 'subs')
+        self.diffusion = cfg_get(config, 'diffusion', 'absorbing_state')
+        self.length = cfg_get(config, 'model.length', 1024)
+
+    def set_length(self, n):
+        self.length = n
+
+    def state_dict(self):
+        return {'backbone.' + k: v for k, v in self._state_dict.items()}
+
+    def eval(self):
+        return self
+
+
+def _instantiate_tokenizer(tokenizer):
+    if isinstance(tokenizer, Tokenizer):
+        return tokenizer
+    return Tokenizer(sequences=True)  # the only tokenizer the configs name (evodiff.utils.Tokenizer)
+
+
+def _load_dit_state(model_name, config):
+    ckpt = os.path.join('checkpoints', str(model_name), 'best_model.ckpt')
+    if os.path.exists(ckpt):
+        return W.load_lightning_state(ckpt, 'backbone.')
+    if str(model_name).startswith('synthetic') or os.environ.get('SGPO_SYNTHETIC_WEIGHTS') == '1':
+        seed = int(os.environ.get('SGPO_SYNTHETIC_SEED', '0'))
+        return W.dit_synthetic_state(
+            seed=seed, vocab=31, hidden=int(cfg_get(config, 'model.hidden_size', 512)),
+            cond_dim=int(cfg_get(config, 'model.cond_dim', 128)), n_blocks=int(cfg_get(config, 'model.n_blocks', 8)),
+            n_heads=int(cfg_get(config, 'model.n_heads', 8)))
+    raise FileNotFoundError(
+        f'{ckpt} not found. Pretrained checkpoints are not shipped; pass model_name="synthetic..." or set '
+        f'SGPO_SYNTHETIC_WEIGHTS=1 for seeded random weights of the configured architecture.')
+
+
+class MDLM(GenerativeModel):
+    def __init__(self, model_name, config, tokenizer, num_steps=128, seq_len=389, device='cuda', state_dict=None,
+                 t_next_mode='reference'):
+        self.tokenizer = _instantiate_tokenizer(tokenizer)
+        dev = rt.init(device if str(device) != 'cuda' else None)
+        sd = state_dict if state_dict is not None else _load_dit_state(model_name, config)
+        self.net = rt.DitDenoiser(sd, device=dev, max_len=max(int(cfg_get(config, 'model.length', 1024)), seq_len))
+        self.model = _Core(self.net, sd, config, self.tokenizer)
+        self.model.set_length(seq_len)
+        self.S = self.model.vocab_size
+        self.timestep = num_steps
+        self.length = seq_len
+        self.device = str(dev)
+        self._dev = dev
+        self.diffusion = cfg_get(config, 'diffusion', 'absorbing_state')
+        self.parameterization = cfg_get(config, 'parameterization', 'subs')
+        self.time_conditioning = bool(cfg_get(config, 'time_conditioning', False))
+        self.t_next_mode = t_next_mode
+        self.noise_source = rt.NoiseSource(seed=torch.initial_seed())
+        self.injected_noise = deque()   # parity runs: tensors consumed by successive sampling calls
+        self._nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    # ------------------------------------------------------------------ noise bookkeeping
+    def reseed(self, seed=None, row_offset=0):
+        """New Philox key (default: torch.initial_seed(), i.e. what util/seed.py:set_seed set)."""
+        self.noise_source = rt.NoiseSource(seed=torch.initial_seed() if seed is None else seed, row_offset=row_offset)
+
+    def _next_noise(self):
+        return self.injected_noise.popleft().to(self._dev, torch.float32) if self.injected_noise else None
+
+    # ------------------------------------------------------------------ schedule
+    def _move_chances(self, t, t_next=None):
+        """(move_chance_t, move_chance_s, sigma_t) as fp32 host scalars (models/mdlm.py:57-68)."""
+        tt = torch.as_tensor(t).detach().cpu().to(torch.float32) / self.timestep
+        if self.t_next_mode == 'reference':
+            tn = tt / self.timestep   # defect D2
+        else:
+            tn = (torch.as_tensor(t).detach().cpu().to(torch.float32) - 1) / self.timestep
+        sig_t, _ = self.model.noise(tt)
+        sig_s, _ = self.model.noise(tn)
+        mt = 1 - torch.exp(-sig_t)
+        ms = 1 - torch.exp(-sig_s)
+        return float(mt), float(ms), sig_t
+
+    def _denoise(self, x, sigma_t=None, out=None):
+        """Raw denoiser logits (B,L,V); sigma only matters under time conditioning."""
+        sig = None
+        if self.time_conditioning and sigma_t is not None:
+            sig = torch.as_tensor(sigma_t, dtype=torch.float32).reshape(-1)[:1].to(self._dev)
+        return self.net.forward(x, sig, out=out)
+
+    # ------------------------------------------------------------------ reference API
+    def sample(self, num_samples):
+        """MDLMDiffusion._sample with the ddpm predictor + noise removal (mdlm_diffusion.py:661-700)."""
+        eps = 1e-5
+        n = self.timestep
+        x = self.get_start(num_samples)
+        timesteps = torch.linspace(1, eps, n + 1)
+        dt = (1 - eps) / n
+        for i in range(n):
+            t = timesteps[i]
+            sig_t, _ = self.model.noise(t)
+            sig_s, _ = self.model.noise(t - dt)
+            mt, ms = float(1 - torch.exp(-sig_t)), float(1 - torch.exp(-sig_s))
+            logits = self._denoise(x, sig_t)
+            x, _ = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_HARD,
+                                        noise_src=self.noise_source, noise=self._next_noise())
+        sig, _ = self.model.noise(timesteps[-1])
+        logits = self._denoise(x, sig)
+        x, _ = rt.reverse_step_mdlm(logits, x, 1.0, 0.0, self.model.mask_index, L.STEP_HARD,
+                                    noise_mode=L.NOISE_NONE)
+        return x
+
+    def get_start(self, batch_size):
+        return torch.full((batch_size, self.length), self.model.mask_index, dtype=torch.int64, device=self._dev)
+
+    @torch.no_grad()
+    def p_sample(self, x, t, t_next=None, hard=True, guidance=None):
+        mt, ms, sig_t = self._move_chances(t)
+        x = x.to(self._dev)
+        logits = self._denoise(x, sig_t)
+        if self.diffusion == 'absorbing_state':
+            if hard:
+                xo, _ = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_HARD,
+                                             noise_src=self.noise_source, noise=self._next_noise())
+                return xo
+            _, q = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_SOFT)
+            return q
+        if self.diffusion == 'uniform':
+            if hard:
+                xo, _ = rt.reverse_step_udlm(logits, x, mt, ms, L.STEP_HARD, noise_src=self.noise_source,
+                                             noise=self._next_noise())
+                return xo
+            _, q = rt.reverse_step_udlm(logits, x, mt, ms, L.STEP_SOFT)
+            return q
+        raise NotImplementedError(f'Diffusion type {self.diffusion} not implemented.')
+
+    def sigma(self, t):
+        sigma, _ = self.model.noise(torch.as_tensor(t) / self.timestep)
+        return sigma
+
+    def q_sample(self, x, t):
+        """Forward noising (models/mdlm.py:104-109); t (B,) integer timesteps."""
+        if self.diffusion != 'absorbing_state':
+            raise NotImplementedError('q_sample: only absorbing-state diffusion is on the HIP path')
+        sig, _ = self.model.noise(torch.as_tensor(t).to(torch.float32).cpu() / self.timestep)
+        mc = 1 - torch.exp(-sig)
+        return rt.q_sample_mdlm(x.to(self._dev), mc, self.model.mask_index, noise_src=self.noise_source,
+                                noise=self._next_noise())
+
+    # ------------------------------------------------------------------ guidance
+    def _jump_log_ratios(self, predictor_model, x, t):
+        """(compact log-ratios (B,n_slots,S), slot_of_pos (L,) int32 or None)."""
+        vf = getattr(predictor_model, 'hip_value_function', None)
+        if vf is not None:
+            vf = vf()
+            lr = vf.jump_log_ratios(x, float(t), self.S)
+            return lr, _slot_map(vf.read_pos, x.shape[1], x.device)
+        return _generic_jump_log_ratios(predictor_model, x, t, self.S), None
+
+    def get_guided_rates(self, predictor_model, x, t, q_t, use_tag=False, guide_temp=1.0,
+                         log_prob_ratio_cutoff=80.0):
+        """Exact classifier-guided rates (models/mdlm.py:340-413).
+
+        The sampling loop does not call this: `Classifier_Guidance_Inpaint.inference` uses the
+        fused kernel.  This entry point keeps the reference signature for other callers.
+        """
+        if guide_temp == 0:
+            return q_t
+        if use_tag:
+            raise NotImplementedError('TAG guidance is never enabled by the reference callers (SURVEY a-5)')
+        lr, slots = self._jump_log_ratios(predictor_model, x, t)
+        if slots is not None:
+            full = torch.zeros(x.shape[0], x.shape[1], self.S, dtype=torch.float32, device=x.device)
+            pos = torch.nonzero(slots >= 0).squeeze(-1)
+            full[:, pos] = lr[:, slots[pos].long()]
+            lr = full
+        q_t = q_t * torch.exp(torch.clamp(lr / guide_temp, max=80))
+        if q_t.isnan().any():
+            raise ValueError("The rate matrix 'q_t' contains NaNs.")
+        return q_t
+
+    @torch.no_grad()
+    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False):
+        """One fused classifier-guidance step (sampling/cls_guidance.py:34-52): denoiser ->
+        jump log-ratios -> reverse-step kernel.  Returns the next tokens (and p if asked)."""
+        mt, ms, sig_t = self._move_chances(t)
+        logits = self._denoise(x, sig_t)
+        lr = slots = None
+        if predictor_model is not None and guide_temp != 0:
+            lr, slots = self._jump_log_ratios(predictor_model, x, t)
+        xo, p = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_SOFT_CG,
+                                     noise_src=self.noise_source, noise=self._next_noise(), log_ratio=lr,
+                                     slot_of_pos=slots, guide_temp=guide_temp, want_probs=want_probs,
+                                     nan_flag=self._nan_flag)
+        return (xo, p) if want_probs else xo
+
+    def check_nan(self):
+        """Mirror of `raise ValueError` at models/mdlm.py:410-411, checked once per inference."""
+        if int(self._nan_flag.item()) != 0:
+            self._nan_flag.zero_()
+            raise ValueError("The rate matrix 'q_t' contains NaNs.")
+
+    def _nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t):
+        from .nos_step import nos_denoise
+        return nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t)
+
+
+_slot_cache = {}
+
+
+def _slot_map(read_pos, Lq, device):
+    key = (tuple(read_pos), Lq, str(device))
+    if key not in _slot_cache:
+        if list(read_pos) == list(range(Lq)):
+            _slot_cache[key] = None
+        else:
+            m = torch.full((Lq,), -1, dtype=torch.int32)
+            for i, p in enumerate(read_pos):
+                m[p] = i
+            _slot_cache[key] = m.to(device)
+    return _slot_cache[key]
+
+
+def _generic_jump_log_ratios(predictor_model, x, t, S, chunk=64):
+    """Reference formulation for arbitrary predictors (e.g. GP samples): materialised single-site
+    jumps, evaluated `chunk` sequences at a time (models/mdlm.py:111-162,360-375)."""
+    B, D = x.shape
+    out = torch.empty(B, D, S, dtype=torch.float32, device=x.device)
+    jump_idx = torch.arange(D * S, device=x.device)
+    dims, states = jump_idx // S, jump_idx % S
+    for b0 in range(0, B, chunk):
+        xb = x[b0:b0 + chunk]
+        n = xb.shape[0]
+        tt = t * torch.ones((n,), device=x.device)
+        lp = predictor_model(xb, tt)
+        xj = xb.unsqueeze(1).repeat(1, D * S, 1)
+        xj[:, jump_idx, dims] = states
+        lpj = predictor_model(xj.view(-1, D), tt.repeat_interleave(D * S)).view(n, D, S)
+        out[b0:b0 + n] = lpj - lp.view(n, 1, 1)
+    return out

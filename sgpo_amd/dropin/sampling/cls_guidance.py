@@ -1,0 +1,62 @@
+"""Drop-in `sampling.cls_guidance.Classifier_Guidance_Inpaint`
+(reference: sampling/cls_guidance.py:7-69).
+
+With the HIP-backed MDLM the per-step chain  p_sample(soft) -> -1 at x ->
+get_guided_rates -> +1 -> clamp -> normalise -> torch.multinomial  is ONE fused
+kernel fed by the denoiser and the jump-ratio kernel (`net.guided_step`).  Any
+other `net` (e.g. D3PM for the round-0 data of pareto.py:48-67) runs the same
+algebra through `net.p_sample` / `net.get_guided_rates`.
+"""
+import torch
+import tqdm
+
+from .base import Algo
+
+
+class Classifier_Guidance_Inpaint(Algo):
+    def __init__(self, net, data_config, forward_op=None, temperature=1, n_max_mutations=None, device='cuda'):
+        super().__init__(net=net, forward_op=forward_op, data_config=data_config, n_max_mutations=n_max_mutations,
+                         device=device)
+        self.temperature = temperature if forward_op is not None else 0.
+
+    def update_model(self, classifier):
+        self.forward_op = classifier.eval()  # make sure the model is in eval mode
+
+    def project(self, x):
+        return x * self.mask + self.full_seq * (1 - self.mask)
+
+    @torch.no_grad()
+    def inference(self, num_samples=1, verbose=False, detokenize=False, inpaint=False):
+        timesteps = torch.linspace(self.net.timestep - 1, 1, int((self.net.timestep - 1) / 1), dtype=int)
+        timesteps = tqdm.tqdm(timesteps) if verbose else timesteps
+        x = self.net.get_start(num_samples)
+        fused = hasattr(self.net, 'guided_step')
+        for t in timesteps:
+            if fused:
+                x = self.net.guided_step(x, t, self.forward_op, self.temperature)
+            else:
+                x = self._generic_step(x, t)
+            if inpaint:
+                x = self.project(x)
+        if fused and hasattr(self.net, 'check_nan'):
+            self.net.check_nan()
+        x = self.project(x)
+        if detokenize:
+            detokenized = self.project_sequences(self._untokenize_batch(x))
+            return x, detokenized
+        return x
+
+    def _generic_step(self, x, t):
+        """sampling/cls_guidance.py:34-52 for nets without a fused step."""
+        from sgpo_amd import runtime as rt
+        p = self.net.p_sample(x, t, hard=False)
+        bi = torch.arange(p.shape[0], device=p.device)[:, None]
+        li = torch.arange(p.shape[1], device=p.device)
+        p[bi, li, x] -= 1
+        p = self.net.get_guided_rates(self.forward_op, x, t, p, guide_temp=self.temperature)
+        p[bi, li, x] += 1
+        p = p.clamp(min=0)
+        p = p / p.sum(dim=-1, keepdim=True)
+        src = getattr(self.net, 'noise_source', None)
+        nz = self.net._next_noise() if hasattr(self.net, '_next_noise') else None
+        return rt.categorical_sample(p, noise_src=src, noise=nz)

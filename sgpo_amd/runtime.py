@@ -187,7 +187,7 @@ def reverse_step_mdlm(logits, x, mt, ms, mask_index, step_mode, noise_src=None, 
         assert noise.dtype == torch.float32
         if noise_mode is None:
             noise_mode = L.NOISE_EXPONENTIAL if step_mode == L.STEP_SOFT_CG else L.NOISE_UNIFORM
-    else:
+    elif noise_mode is None:
         noise_mode = L.NOISE_PHILOX
     seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
     probs = torch.empty_like(logits) if (want_probs or step_mode == L.STEP_SOFT) else None
