@@ -56,7 +56,7 @@ def build(device, batch, dit_seed=0, mlp_seed=1):
     return net, pred, algo, sd, msd
 
 
-def cpu_baseline(sd, msd, n_seq=4, n_steps=16):
+def cpu_baseline(sd, msd, n_seq=8, n_steps=48):
     """The CPU oracle (reference formulation incl. materialised jumps) on a bounded sample:
     n_seq sequences x the first n_steps of the 127 reverse steps, scaled to whole sequences."""
     from oracle import cls_guidance as ocg

@@ -63,6 +63,9 @@ def load():
         if not os.path.exists(LIB_PATH):
             raise SgpoError(f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                             f'or `make -C sgpo_amd/csrc`. There is no CPU fallback.')
+        # torch first: libsgpo_hip.so must bind to the HIP runtime PyTorch-ROCm ships (same soname);
+        # loading ours first pulls /opt/rocm's copy under torch and the GPU is no longer detected.
+        import torch  # noqa: F401
         lib = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(lib, name)
