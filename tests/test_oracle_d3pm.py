@@ -1,0 +1,99 @@
+"""CPU: oracle restatements of the D3PM wrapper and the DAPS loop vs goldens captured from the
+reference import (models/d3pm.py, sampling/daps.py).  The denoiser inside is the oracle's own
+ByteNet restatement (third party upstream, parity unpinned) -- the goldens store its logits, so
+the wrapper arithmetic is pinned independently of it."""
+import torch
+
+from conftest import load_golden
+from oracle import bytenet as obn
+from oracle import d3pm as od3pm
+from oracle import daps as odaps
+from oracle import mlp as omlp
+from sgpo_amd import weights as W
+
+BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
+S = 26
+
+
+def _sched():
+    Q_bar, Q = od3pm.q_random_schedule(S, 500)
+    return Q, Q_bar, od3pm.sigma_from_qbar(Q_bar, S)
+
+
+def test_schedule_and_sigma():
+    g = load_golden('d3pm_small')
+    Q, Q_bar, sigma = _sched()
+    assert torch.equal(sigma, g['sigma'])            # incl. sigma[499] = +inf (fp64 product cast to fp32)
+    assert torch.isinf(sigma[499]) and abs(float(sigma[1]) - 0.0040) < 1e-4 and abs(float(sigma[250]) - 0.6972) < 1e-3
+    # fp32 accumulation gives the finite variant
+    qb32, _ = od3pm.q_random_schedule(S, 500, accumulate='fp32')
+    s32 = od3pm.sigma_from_qbar(qb32, S)
+    assert torch.isfinite(s32[:499]).all()
+
+
+def test_p_sample_and_q_sample():
+    g = load_golden('d3pm_small')
+    Q, Q_bar, sigma = _sched()
+    sd = W.bytenet_synthetic_state(seed=int(g['bn_seed']), **BN_SMALL)
+    x = g['x']
+    for tag in 'abcde':
+        t, tn = int(g[f't_{tag}'][0]), int(g[f't_{tag}'][1])
+        tn = None if tn < 0 else tn
+        logits = obn.bytenet_forward(sd, x, torch.tensor([t] * x.shape[0]))
+        torch.testing.assert_close(logits, g[f'logits_{tag}'], rtol=1e-5, atol=1e-6)
+        p = od3pm.p_sample(g[f'logits_{tag}'], x, t, tn, Q, Q_bar, sigma, S, hard=False)
+        torch.testing.assert_close(p, g[f'soft_{tag}'], rtol=1e-12, atol=1e-15)
+        xh = od3pm.p_sample(g[f'logits_{tag}'], x, t, tn, Q, Q_bar, sigma, S, e=g[f'e_{tag}'])
+        assert torch.equal(xh, g[f'hard_{tag}'])
+    xq = od3pm.q_sample(x, g['tq'], Q_bar, S, g['eq'])
+    assert torch.equal(xq, g['q_sample'])
+
+
+def test_metropolis_hasting():
+    g = load_golden('daps_small')
+    res1 = [int(r) for r in g['residues']]
+    msd = W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res1))
+    pred = omlp.Predictor(msd, res1)           # reads the 1-indexed list raw (defect D3)
+    residues0 = [r - 1 for r in res1]          # MH proposes on the 0-indexed list
+    L = g['x0hat'].shape[1]
+    for tag in ('lo', 'hi', 'inf'):
+        xo = odaps.metropolis_hasting(g['x0hat'], pred.log_likelihood, torch.as_tensor(g[f'sigma_{tag}']), g['r_idx'].shape[0], 128.,
+                                      1000, residues0, S, L, g['r_idx'], g['r_val'], g['r_u'])
+        assert torch.equal(xo, g[f'mh_{tag}']), tag
+    assert (g['mh_inf'] != g['x0hat']).any()   # some proposals were accepted
+    ts = odaps.time_steps(500, 50)
+    assert torch.equal(ts, g['time_steps']) and ts[0] == 499 and ts[1] == 488 and ts[-1] == 1
+
+
+def test_daps_inference_tiny():
+    g = load_golden('daps_small')
+    Q, Q_bar, sigma = _sched()
+    res1 = [int(r) for r in g['residues']]
+    msd = W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res1))
+    pred = omlp.Predictor(msd, res1)
+    residues0 = [r - 1 for r in res1]
+    sd = W.bytenet_synthetic_state(seed=int(g['bn_seed']), **BN_SMALL)
+    ts = g['inf_time_steps']
+    xt = g['inf_start']
+    B, L = xt.shape
+    full = torch.tensor([W_ALPHA.index(c) for c in bytes(g['full_seq'].numpy().tolist()).decode()])
+    mask = torch.zeros(L, dtype=torch.int64)
+    mask[residues0] = 1
+
+    def denoise(x, t):
+        return obn.bytenet_forward(sd, x, torch.tensor([t] * x.shape[0]))
+
+    n = len(ts)
+    for i in range(n):
+        x0hat = odaps.uncond_sample(denoise, xt, ts[i], 4, Q, Q_bar, sigma, S, g[f'inf_ode_e_{i}'])
+        x0y = odaps.metropolis_hasting(x0hat, pred.log_likelihood, sigma[ts[i]], 25, 128., 1000, residues0, S, L,
+                                       g[f'inf_mh_idx_{i}'], g[f'inf_mh_val_{i}'], g[f'inf_mh_u_{i}'])
+        if i == n - 1:
+            xt = x0y
+            break
+        xt = od3pm.q_sample(x0y, ts[i + 1].repeat(B), Q_bar, S, g[f'inf_q_e_{i}'])
+    xt = xt * mask + full * (1 - mask)
+    assert torch.equal(xt, g['inf_x'])
+
+
+W_ALPHA = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'

@@ -225,7 +225,118 @@ def gen_cg():
              full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
 
 
-GENS = dict(dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg)
+BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
+
+
+def build_ref_d3pm(L, bn_seed=41):
+    """Reference D3PM wrapper (models/d3pm.py) around a stand-in denoiser: the oracle's ByteNet
+    restatement with small seeded weights.  Q / Q_bar come from the restated q_random_schedule."""
+    import models.d3pm as ref_d3pm
+    from oracle import bytenet as obn
+    sd = W.bytenet_synthetic_state(seed=bn_seed, **BN_SMALL)
+    net = object.__new__(ref_d3pm.D3PM)
+    tok = standins.Tokenizer()
+    Q_bar, Q = tok.q_random_schedule(timesteps=500)
+    net.S = tok.K
+    net.model = lambda x, t: obn.bytenet_forward(sd, x, t)
+    net.tokenizer = tok
+    net.scheme = 'd3pm'
+    net.timestep = 500
+    net.Q_bar = Q_bar[:, :net.S, :net.S]
+    net.Q = Q[:, :net.S, :net.S]
+    net.device = 'cpu'
+    net.length = L
+    net.sigma = -torch.log(((net.Q_bar[:, 0, 0] - 1 / net.S) * net.S / (net.S - 1)))  # models/d3pm.py:29
+    return net, sd
+
+
+def gen_d3pm():
+    from oracle import bytenet as obn
+    N, L, S = 3, 20, 26
+    net, sd = build_ref_d3pm(L)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, S, (N, L), generator=g)
+    out = dict(bn_seed=41, x=x, sigma=net.sigma)
+    with torch.no_grad():
+        for tag, t, tn in (('a', 300, None), ('b', 300, 250), ('c', 499, 472), ('d', 26, 0), ('e', 1, None)):
+            out[f'logits_{tag}'] = net.model(x, torch.tensor([t] * N))
+            out[f'soft_{tag}'] = net.p_sample(x, t, tn, hard=False)
+            torch.manual_seed(300 + t)
+            e = torch.empty(N * L, S, dtype=torch.float64).exponential_(1)
+            torch.manual_seed(300 + t)
+            out[f'hard_{tag}'] = net.p_sample(x, t, tn, hard=True)
+            out[f'e_{tag}'] = e
+            out[f't_{tag}'] = np.array([t, -1 if tn is None else tn])
+        tq = torch.tensor([3, 250, 499])
+        torch.manual_seed(17)
+        eq = torch.empty(N * L, S).exponential_(1)
+        torch.manual_seed(17)
+        out['q_sample'] = net.q_sample(x, tq)
+        out['tq'] = tq
+        out['eq'] = eq
+    save('d3pm_small', **out)
+
+
+def gen_daps():
+    """DAPS.metropolis_hasting and a tiny DAPS.inference on the reference (sampling/daps.py)."""
+    from sampling.daps import DAPS
+    N, L, S = 4, 40, 26
+    residues_1idx = [5, 6, 7, 20, 21, 33]
+    net, bsd = build_ref_d3pm(L)
+    full = CREILOV[:L]
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=full,
+                               residues=residues_1idx))
+    pred, msd = build_ref_mlp(len(residues_1idx), residues_1idx, seed=35, full_len=L)
+    algo = DAPS(net, forward_op=pred, num_steps=3, ode_steps=4, mh_steps=25, alpha=128., max_dist=1, beta=1000,
+                data_config=dc, device='cpu')
+    n_res = len(algo.residues)
+    g = torch.Generator().manual_seed(9)
+    x0hat = torch.randint(0, S, (N, L), generator=g)
+    steps = 60
+    out = dict(mlp_seed=35, bn_seed=41, residues=np.array(residues_1idx), x0hat=x0hat,
+               full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
+    for tag, sig in (('lo', net.sigma[11]), ('hi', net.sigma[400]), ('inf', net.sigma[499])):
+        torch.manual_seed(55)
+        r_idx, r_val, r_u = [], [], []
+        for _ in range(steps):
+            r_idx.append(torch.randint(n_res, (N,)))
+            r_val.append(torch.randint(S, (N,)))
+            r_u.append(torch.rand(N))
+        torch.manual_seed(55)
+        with torch.no_grad():
+            xo = algo.metropolis_hasting(x0hat, pred, None, sig, steps=steps, alpha=algo.alpha)
+        out[f'mh_{tag}'] = xo
+        out[f'sigma_{tag}'] = sig
+    out['r_idx'], out['r_val'], out['r_u'] = torch.stack(r_idx), torch.stack(r_val), torch.stack(r_u)
+    out['time_steps'] = DAPS(net, forward_op=pred, num_steps=50, ode_steps=20, data_config=dc, device='cpu').time_steps
+
+    # tiny full inference: record every draw in call order
+    B = 2
+    torch.manual_seed(91)
+    rec = {}
+    rec['start'] = torch.randint(0, S, (B, L))
+    ts = algo.time_steps
+    for i in range(algo.num_steps):
+        rec[f'ode_e_{i}'] = torch.stack([torch.empty(B * L, S, dtype=torch.float64).exponential_(1)
+                                         for _ in range(algo.ode_steps - 1)])
+        a, b, c = [], [], []
+        for _ in range(algo.mh_steps):
+            a.append(torch.randint(n_res, (B,)))
+            b.append(torch.randint(S, (B,)))
+            c.append(torch.rand(B))
+        rec[f'mh_idx_{i}'], rec[f'mh_val_{i}'], rec[f'mh_u_{i}'] = torch.stack(a), torch.stack(b), torch.stack(c)
+        if i < algo.num_steps - 1:
+            rec[f'q_e_{i}'] = torch.empty(B * L, S).exponential_(1)
+    torch.manual_seed(91)
+    with torch.no_grad():
+        xf = algo.inference(num_samples=B, verbose=False)
+    out.update({'inf_' + k: v for k, v in rec.items()})
+    out['inf_x'] = xf
+    out['inf_time_steps'] = ts
+    save('daps_small', **out)
+
+
+GENS = dict(dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
