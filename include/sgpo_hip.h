@@ -133,6 +133,59 @@ size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B);
 int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- D3PM denoiser: evodiff.model.ByteNetLMTime (third party; call site models/d3pm.py:34-37,
+ * hyper-parameters configs/pretrain_model/d3pm.yaml:12-27) -- restated, parity unpinned ----------
+ * blob (fp32, device), state_dict order: embedder.embedder.weight, embedder.up_embedder.conv.{weight,bias},
+ * per layer n: sequence1.0.{weight,bias}, sequence1.2.conv.{weight,bias}, sequence1.3.{weight,bias},
+ * conv.{weight,bias} ([out][in][tap]), sequence2.0.{weight,bias}, sequence2.2.conv.{weight,bias};
+ * decoder.conv.{weight,bias}. */
+typedef struct {
+  int n_tokens;    /* 31 */
+  int d_embedding; /* 8 */
+  int d_model;     /* 1024 */
+  int d_h;         /* 512 (slim) */
+  int n_layers;    /* 16 */
+  int kernel_size; /* 5 */
+  int r;           /* 128: dilation of layer n = 2^(n mod (log2(r)+1)) */
+} sgpo_bytenet_config;
+size_t sgpo_bytenet_param_count(const sgpo_bytenet_config* cfg);
+int sgpo_bytenet_create(const sgpo_bytenet_config* cfg, const float* blob, size_t n_floats, sgpo_bytenet** out);
+void sgpo_bytenet_destroy(sgpo_bytenet* m);
+size_t sgpo_bytenet_workspace_bytes(const sgpo_bytenet* m, int B, int L);
+/* tokens [B][L]; t [n_t] int64 timesteps (n_t = 1 broadcasts); logits [B][L][n_tokens] fp32;
+ * hidden_out optional [B][L][d_model]. */
+int sgpo_bytenet_forward(sgpo_bytenet* m, const int64_t* tokens, const int64_t* t, int n_t, int B, int L,
+                         float* logits, float* hidden_out, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- D3PM reverse step: D3PM.p_sample (models/d3pm.py:230-268) -------------------------------
+ * logits [N][L][ld_logits] fp32 (first S columns used, pred_mean models/d3pm.py:34-37);
+ * delta_q [S][S] fp32 = Q[t] or the analytic e^{dsigma} I + (1-e^{dsigma})/S (models/d3pm.py:239-243);
+ * q_bar [S][S] fp32 = Q_bar[t-1] or Q_bar[t_next] (models/d3pm.py:250-253); both chosen by the host.
+ * SOFT: probs_out [N][L][S] fp64 (normalised posterior).  HARD: x_out; noise (noise_mode 1) is an
+ * fp64 [N][L][S] tensor of Exp(1) draws (torch.multinomial on fp64 probabilities). */
+int sgpo_reverse_step_d3pm(const float* logits, int ld_logits, const int64_t* x, int N, int L, int S,
+                           const float* delta_q, const float* q_bar, int step_mode, int noise_mode,
+                           const void* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
+                           int64_t* x_out, double* probs_out, void* stream);
+/* D3PM.q_sample (models/d3pm.py:45-52): t [B] int64; q_bar_all [T][S][S] fp32; noise fp32 [B][L][S] Exp(1). */
+int sgpo_q_sample_d3pm(const int64_t* x, const int64_t* t, const float* q_bar_all, int T, int B, int L, int S,
+                       int noise_mode, const float* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
+                       int64_t* x_out, void* stream);
+
+/* ---- DAPS Metropolis-Hastings: DAPS.metropolis_hasting + log_ratio (sampling/daps.py:68-114) ----
+ * `steps` sequential proposals per sequence in one launch.  residues / res_slot: DEVICE int32
+ * [n_res] = mutable positions (0-indexed, sampling/base.py:30) and the read slot of each in the value
+ * function (or -1: defect D3 makes some proposals invisible to it).  log_alpha / log_1alpha: the
+ * two scalars of log_ratio (daps.py:69-71) from sigma/beta, computed by the host in fp32.
+ * Injected noise (noise_mode != 0): r_idx/r_val int32 [steps][N], r_u fp32 [steps][N].
+ * x_out must not alias x0hat.  workspace: sgpo_daps_mh_workspace_bytes(). */
+size_t sgpo_daps_mh_workspace_bytes(void);
+int sgpo_daps_mh(sgpo_mlp* m, const int64_t* x0hat, int N, int L, int S, const int* residues,
+                 const int* res_slot, int n_res, float log_alpha, float log_1alpha, float alpha, int steps,
+                 int noise_mode, const int* r_idx, const int* r_val, const float* r_u, uint64_t seed,
+                 uint64_t offset, uint64_t row_offset, int64_t* x_out, void* workspace,
+                 size_t workspace_bytes, void* stream);
+
 /* ---- test / bench access to the building blocks ----------------------------------- */
 /* C[M][N] (fp32) = A[M][K] (bf16) * W[N][K]^T (bf16) through the MFMA GEMM kernel. */
 int sgpo_gemm_bf16(const void* A, const void* W, float* C, int M, int N, int K, void* stream);

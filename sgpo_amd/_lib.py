@@ -45,6 +45,16 @@ SIGNATURES = {
     'sgpo_mlp_forward': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     'sgpo_mlp_workspace_bytes': (_sz, [_vp, _i]),
     'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'sgpo_bytenet_param_count': (_sz, [_vp]),
+    'sgpo_bytenet_create': (_i, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    'sgpo_bytenet_destroy': (None, [_vp]),
+    'sgpo_bytenet_workspace_bytes': (_sz, [_vp, _i, _i]),
+    'sgpo_bytenet_forward': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _sz, _vp]),
+    'sgpo_reverse_step_d3pm': (_i, [_vp, _i, _vp, _i, _i, _i, _vp, _vp, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    'sgpo_q_sample_d3pm': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp]),
+    'sgpo_daps_mh_workspace_bytes': (_sz, []),
+    'sgpo_daps_mh': (_i, [_vp, _vp, _i, _i, _i, _vp, _vp, _i, _f, _f, _f, _i, _i, _vp, _vp, _vp, _u64, _u64, _u64,
+                          _vp, _vp, _sz, _vp]),
     'sgpo_gemm_bf16': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'sgpo_f32_to_bf16': (_i, [_vp, _vp, _sz, _vp]),
     'sgpo_prof_enable': (_i, [_i, _i]),
@@ -89,3 +99,7 @@ def ptr(t):
 def stream_ptr():
     import torch
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+class BytenetConfig(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ('n_tokens', 'd_embedding', 'd_model', 'd_h', 'n_layers', 'kernel_size', 'r')]

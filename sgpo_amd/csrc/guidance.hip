@@ -16,22 +16,7 @@
 #include "../../include/sgpo_hip.h"
 #include "common.h"
 #include "prof.h"
-
-#define MH 64  // hidden width (problem/protein.py: hidden_dim 64)
-
-struct sgpo_mlp {
-  int n_read = 0, alphabet = 0, hidden = 0, time_cond = 0;
-  int* read_pos = nullptr;     // [n_read] device
-  float* params = nullptr;     // raw blob copy
-  float* T1 = nullptr;         // [n_read][alphabet][64]
-  float* be1 = nullptr;        // [64] b1 + sum_i W1_i be
-  float* w1t_time = nullptr;   // [k][j] = W1[j][n_read*64 + k]
-  float* wt_lin_t = nullptr;   // [k][j] = time_embedder.1.weight[j][k]
-  float* w_t[3] = {nullptr, nullptr, nullptr};  // transposed 64x64 layers (mlp.2, mlp.4, cls_head.0): [k][j]
-  float* w_perm = nullptr;     // the three layers permuted for the MFMA A operand: [layer][to][ti][r][h][i]
-  float* bias_perm = nullptr;  // [layer][t][r][h] biases in accumulator order (3 layers) + w5 in the same order
-  const float *tW, *bt, *b2, *b3, *b4, *w5, *b5;
-};
+#include "mlp.h"
 
 // ---- setup kernels ---------------------------------------------------------
 __global__ void mlp_table_kernel(const float* __restrict__ W1, int in_dim, const float* __restrict__ E /*[64][A]*/,
@@ -83,6 +68,7 @@ extern "C" void sgpo_mlp_destroy(sgpo_mlp* m) {
   (void)hipFree(m->w1t_time); (void)hipFree(m->wt_lin_t);
   for (int i = 0; i < 3; ++i) (void)hipFree(m->w_t[i]);
   (void)hipFree(m->w_perm); (void)hipFree(m->bias_perm);
+  delete[] m->read_pos_host;
   delete m;
 }
 
@@ -102,6 +88,8 @@ extern "C" int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, c
   HIPF(hipMemcpy(m->params, blob, n_floats * 4, hipMemcpyDeviceToDevice));
   HIPF(hipMalloc((void**)&m->read_pos, n_read * sizeof(int)));
   HIPF(hipMemcpy(m->read_pos, read_pos, n_read * sizeof(int), hipMemcpyHostToDevice));
+  m->read_pos_host = new int[n_read];
+  for (int i = 0; i < n_read; ++i) m->read_pos_host[i] = read_pos[i];
   HIPF(hipMalloc((void**)&m->T1, (size_t)n_read * A * h * 4));
   HIPF(hipMalloc((void**)&m->be1, h * 4));
   HIPF(hipMalloc((void**)&m->w1t_time, h * h * 4));
@@ -118,6 +106,7 @@ extern "C" int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, c
   const float* W2 = take(h * h); m->b2 = take(h);
   const float* W3 = take(h * h); m->b3 = take(h);
   const float* W4 = take(h * h); m->b4 = take(h);
+  m->W2 = W2; m->W3 = W3; m->W4 = W4;
   m->w5 = take(h); m->b5 = take(1);
   const int nT = n_read * (int)A * MH;
   hipLaunchKernelGGL(mlp_table_kernel, dim3((nT + 255) / 256), dim3(256), 0, 0, W1, (int)in_dim, E, (int)A, n_read, m->T1);

@@ -1,0 +1,124 @@
+"""Drop-in `sampling.daps.DAPS` (reference: sampling/daps.py:9-164).
+
+The annealing loop stays on the host; each of its three stages is a library call:
+few-step reverse "ODE" (`net.p_sample`, denoiser + fused posterior kernel), the whole
+Metropolis-Hastings chain of `mh_steps` proposals in ONE kernel launch
+(`sgpo_daps_mh`, replacing 1000 dispatch-bound PyTorch steps), and `net.q_sample`.
+Predictors other than the MLP value function (e.g. GP samples) run the reference's
+step-by-step formulation on the device through torch.
+"""
+from collections import deque
+
+import torch
+import tqdm
+
+from models.d3pm import D3PM
+from models.mdlm import MDLM
+
+from .base import Algo
+
+
+class DAPS(Algo):
+    def __init__(self, net, forward_op=None, num_steps=200, ode_steps=64, mh_steps=1000, alpha=1, beta=1, max_dist=1,
+                 data_config=None, n_max_mutations=None, device='cuda'):
+        super().__init__(net=net, forward_op=forward_op, data_config=data_config, n_max_mutations=n_max_mutations,
+                         device=device)
+        self.type = 'D3PM' if type(net) == D3PM else 'MDLM'
+        self.num_steps = num_steps
+        self.time_steps = torch.linspace(self.net.timestep - 1, 1, self.num_steps, dtype=int)
+        self.ode_steps = ode_steps
+        self.mh_steps = mh_steps
+        self.alpha = alpha if forward_op is not None else 0.
+        self.max_dist = max_dist
+        self.beta = beta
+        self.injected_mh = deque()   # parity runs: (r_idx, r_val, r_u) per metropolis_hasting call
+
+    def update_model(self, classifier):
+        self.forward_op = classifier.eval()
+
+    def project(self, x):
+        return x * self.mask + self.full_seq * (1 - self.mask)
+
+    def log_ratio(self, sigma, hm_dist):
+        alpha = (1 - torch.exp(-sigma)) * (1 - 1 / self.net.S)
+        log_alpha = torch.log(alpha + 1e-5)
+        log_1alpha = torch.log(1 - alpha)
+        return hm_dist * log_alpha + (self.net.length - hm_dist) * log_1alpha
+
+    def _log_ratio_scalars(self, sigma):
+        """(log_alpha, log_1alpha) of log_ratio (daps.py:69-71) as fp32 host scalars."""
+        s = torch.as_tensor(sigma, dtype=torch.float32).detach().cpu() / self.beta
+        a = (1 - torch.exp(-s)) * (1 - 1 / self.net.S)
+        return float(torch.log(a + 1e-5)), float(torch.log(1 - a))
+
+    @torch.no_grad()
+    def metropolis_hasting(self, x0hat, op, y, sigma, steps, alpha, inpaint=False):
+        if self.max_dist != 1:
+            raise NotImplementedError('max_dist != 1: the reference loop keeps only the last proposal anyway')
+        vf = getattr(op, 'hip_value_function', None)
+        if vf is None:
+            return self._metropolis_hasting_generic(x0hat, op, y, sigma, steps, alpha)
+        from sgpo_amd import runtime as rt
+        la, l1a = self._log_ratio_scalars(sigma)
+        inj = self.injected_mh.popleft() if self.injected_mh else (None, None, None)
+        return rt.daps_mh(vf(), x0hat, self.residues, self.net.S, la, l1a, alpha, steps,
+                          noise_src=getattr(self.net, 'noise_source', None), r_idx=inj[0], r_val=inj[1], r_u=inj[2])
+
+    def _metropolis_hasting_generic(self, x0hat, op, y, sigma, steps, alpha):
+        """sampling/daps.py:75-114 verbatim in structure, for arbitrary `op.log_likelihood`."""
+        residues = torch.tensor(self.residues, device=x0hat.device)
+        n_res = residues.shape[0]
+        x = x0hat.clone()
+        dim = self.net.S
+        N = x0hat.shape[0]
+        sigma = torch.as_tensor(sigma, device=x0hat.device)
+        cur_ll = op.log_likelihood(x, y) * alpha
+        cur_hm = (x != x0hat).sum(dim=-1)
+        for _ in range(steps):
+            proposal = x.clone()
+            idx = residues[torch.randint(n_res, (N,), device=x.device)]
+            v = torch.randint(dim, (N,), device=x.device)
+            proposal.scatter_(1, idx[:, None], v.unsqueeze(1))
+            ll = op.log_likelihood(proposal, y) * alpha
+            hm = (proposal != x0hat).sum(dim=-1)
+            lr = ll - cur_ll
+            lr += self.log_ratio(sigma / self.beta, hm) - self.log_ratio(sigma / self.beta, cur_hm)
+            rho = torch.clip(torch.exp(lr), max=1.0)
+            seed = torch.rand_like(rho)
+            x = x * (seed > rho).unsqueeze(-1) + proposal * (seed < rho).unsqueeze(-1)
+            cur_ll = ll * (seed < rho) + cur_ll * (seed > rho)
+            cur_hm = hm * (seed < rho) + cur_hm * (seed > rho)
+        return x
+
+    def uncond_sample(self, net, xt, t_start, inpaint=False):
+        timesteps = torch.linspace(int(t_start), 0, self.ode_steps, dtype=int)
+        for t, t_next in zip(timesteps[:-1], timesteps[1:]):
+            xt = net.p_sample(xt, t, t_next)
+            if inpaint:
+                xt = self.project(xt)
+        return xt
+
+    @torch.no_grad()
+    def inference(self, observation=None, num_samples=1, verbose=True, detokenize=False, inpaint=False):
+        pbar = tqdm.trange(self.num_steps) if verbose else range(self.num_steps)
+        xt = self.net.get_start(num_samples)
+        for i in pbar:
+            x0hat = self.uncond_sample(self.net, xt, self.time_steps[i], inpaint)
+            if self.type == 'D3PM':
+                sigma = self.net._sigma_cpu[self.time_steps[i]] if hasattr(self.net, '_sigma_cpu') \
+                    else self.net.sigma[self.time_steps[i]]
+            else:
+                sigma = self.net.sigma(self.time_steps[i])
+            if self.alpha == 0:
+                x0y = x0hat
+            else:
+                x0y = self.metropolis_hasting(x0hat, self.forward_op, observation, sigma, steps=self.mh_steps,
+                                              alpha=self.alpha, inpaint=inpaint)
+            if i == self.num_steps - 1:
+                xt = x0y
+                break
+            xt = self.net.q_sample(x0y, self.time_steps[i + 1].repeat(num_samples))
+        xt = self.project(xt)
+        if detokenize:
+            return xt, self.project_sequences(self._untokenize_batch(xt))
+        return xt

@@ -261,3 +261,133 @@ def gemm_bf16(a, w):
     out = torch.empty(M, N, dtype=torch.float32, device=a.device)
     L.check(lib.sgpo_gemm_bf16(L.ptr(a16), L.ptr(w16), L.ptr(out), M, N, K, L.stream_ptr()), 'sgpo_gemm_bf16')
     return out
+
+
+BN_LAYER_ORDER = ['sequence1.0.weight', 'sequence1.0.bias', 'sequence1.2.conv.weight', 'sequence1.2.conv.bias',
+                  'sequence1.3.weight', 'sequence1.3.bias', 'conv.weight', 'conv.bias', 'sequence2.0.weight',
+                  'sequence2.0.bias', 'sequence2.2.conv.weight', 'sequence2.2.conv.bias']
+
+
+class BytenetDenoiser:
+    """ByteNetLMTime forward on the GPU (third-party architecture restated; parity unpinned)."""
+
+    def __init__(self, state_dict, r=128, device=None):
+        self.device = init(device)
+        self.lib = L.load()
+        sd = state_dict
+        n_tokens, d_emb = sd['embedder.embedder.weight'].shape
+        d_model = sd['embedder.up_embedder.conv.weight'].shape[0]
+        d_h, _, ks = sd['embedder.layers.0.conv.weight'].shape
+        n_layers = 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('embedder.layers.'))
+        self.n_tokens, self.d_model = n_tokens, d_model
+        self.cfg = L.BytenetConfig(n_tokens, d_emb, d_model, d_h, n_layers, ks, r)
+        keys = ['embedder.embedder.weight', 'embedder.up_embedder.conv.weight', 'embedder.up_embedder.conv.bias']
+        keys += [f'embedder.layers.{n}.{k}' for n in range(n_layers) for k in BN_LAYER_ORDER]
+        keys += ['decoder.conv.weight', 'decoder.conv.bias']
+        blob = _blob(sd, keys, self.device)
+        n = self.lib.sgpo_bytenet_param_count(C.byref(self.cfg))
+        if blob.numel() != n:
+            raise L.SgpoError(f'ByteNet state dict has {blob.numel()} parameters, library expects {n}')
+        h = C.c_void_p()
+        L.check(self.lib.sgpo_bytenet_create(C.byref(self.cfg), L.ptr(blob), blob.numel(), C.byref(h)),
+                'sgpo_bytenet_create')
+        self.handle = h
+        self.ws = Workspace(self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.sgpo_bytenet_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, tokens, t, return_hidden=False, out=None):
+        """tokens (B,L) int64, t int / (1,) / (B,) int64 timesteps -> logits (B,L,n_tokens) fp32."""
+        B, Lq = tokens.shape
+        tokens = tokens.contiguous()
+        t = torch.as_tensor(t, dtype=torch.int64).reshape(-1).to(self.device).contiguous()
+        need = self.lib.sgpo_bytenet_workspace_bytes(self.handle, B, Lq)
+        ws = self.ws.get(need)
+        base = (ws.data_ptr() + 255) & ~255
+        logits = out if out is not None else torch.empty(B, Lq, self.n_tokens, dtype=torch.float32, device=self.device)
+        hidden = torch.empty(B, Lq, self.d_model, dtype=torch.float32, device=self.device) if return_hidden else None
+        L.check(self.lib.sgpo_bytenet_forward(self.handle, L.ptr(tokens), L.ptr(t), t.numel(), B, Lq, L.ptr(logits),
+                                              L.ptr(hidden), C.c_void_p(base), need, L.stream_ptr()),
+                'sgpo_bytenet_forward')
+        return (logits, hidden) if return_hidden else logits
+
+
+def reverse_step_d3pm(logits, x, delta_q, q_bar, S, hard=True, noise_src=None, noise=None):
+    """D3PM.p_sample given denoiser logits.  noise: fp64 (N,L,S) Exp(1) draws (parity runs)."""
+    lib = L.load()
+    N, Lq, ld = logits.shape
+    logits, x = logits.contiguous(), x.contiguous()
+    delta_q = delta_q.to(logits.device, torch.float32).contiguous()
+    q_bar = q_bar.to(logits.device, torch.float32).contiguous()
+    mode = L.STEP_HARD if hard else L.STEP_SOFT
+    if noise is not None:
+        noise = noise.to(logits.device, torch.float64).contiguous()
+        noise_mode = L.NOISE_EXPONENTIAL
+    else:
+        noise_mode = L.NOISE_PHILOX
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if (noise_src and hard) else (0, 0, 0)
+    x_out = torch.empty_like(x) if hard else None
+    probs = None if hard else torch.empty(N, Lq, S, dtype=torch.float64, device=logits.device)
+    L.check(lib.sgpo_reverse_step_d3pm(L.ptr(logits), ld, L.ptr(x), N, Lq, S, L.ptr(delta_q), L.ptr(q_bar), mode,
+                                       noise_mode, L.ptr(noise), seed, off, row_off * Lq, L.ptr(x_out), L.ptr(probs),
+                                       L.stream_ptr()), 'sgpo_reverse_step_d3pm')
+    return x_out if hard else probs
+
+
+def q_sample_d3pm(x, t, q_bar_all, S, noise_src=None, noise=None):
+    lib = L.load()
+    B, Lq = x.shape
+    x = x.contiguous()
+    t = torch.as_tensor(t, dtype=torch.int64).reshape(-1).to(x.device).contiguous()
+    assert t.numel() == B and q_bar_all.is_cuda and q_bar_all.dtype == torch.float32 and q_bar_all.is_contiguous()
+    if noise is not None:
+        noise = noise.to(x.device, torch.float32).contiguous()
+        noise_mode = L.NOISE_EXPONENTIAL
+    else:
+        noise_mode = L.NOISE_PHILOX
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    out = torch.empty_like(x)
+    L.check(lib.sgpo_q_sample_d3pm(L.ptr(x), L.ptr(t), L.ptr(q_bar_all), q_bar_all.shape[0], B, Lq, S, noise_mode,
+                                   L.ptr(noise), seed, off, row_off * Lq, L.ptr(out), L.stream_ptr()),
+            'sgpo_q_sample_d3pm')
+    return out
+
+
+_mh_ws = {}
+
+
+def daps_mh(vf, x0hat, residues, S, log_alpha, log_1alpha, alpha, steps, noise_src=None, r_idx=None, r_val=None,
+            r_u=None):
+    """DAPS.metropolis_hasting on the GPU.  vf: MlpValueFunction; residues: 0-indexed mutable positions."""
+    lib = L.load()
+    N, Lq = x0hat.shape
+    x0hat = x0hat.contiguous()
+    dev = x0hat.device
+    key = (id(vf), tuple(residues), str(dev))
+    if key not in _mh_ws:
+        slot = [vf.read_pos.index(r) if r in vf.read_pos else -1 for r in residues]
+        _mh_ws[key] = (torch.tensor(list(residues), dtype=torch.int32, device=dev),
+                       torch.tensor(slot, dtype=torch.int32, device=dev),
+                       torch.empty(512, dtype=torch.uint8, device=dev))
+    d_res, d_slot, ws = _mh_ws[key]
+    base = (ws.data_ptr() + 255) & ~255
+    if r_idx is not None:
+        noise_mode = L.NOISE_UNIFORM
+        r_idx = r_idx.to(dev, torch.int32).contiguous()
+        r_val = r_val.to(dev, torch.int32).contiguous()
+        r_u = r_u.to(dev, torch.float32).contiguous()
+    else:
+        noise_mode = L.NOISE_PHILOX
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    out = torch.empty_like(x0hat)
+    L.check(lib.sgpo_daps_mh(vf.handle, L.ptr(x0hat), N, Lq, S, L.ptr(d_res), L.ptr(d_slot), len(residues),
+                             float(log_alpha), float(log_1alpha), float(alpha), int(steps), noise_mode, L.ptr(r_idx),
+                             L.ptr(r_val), L.ptr(r_u), seed, off, row_off, L.ptr(out), C.c_void_p(base), 256,
+                             L.stream_ptr()), 'sgpo_daps_mh')
+    return out
