@@ -133,6 +133,24 @@ size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B);
 int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
                             void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb
+ * (dit.py:494-515: mean-pool over L + Linear(hidden, 1); w_cls = its weight, [hidden] fp32).
+ * One backbone pass, then num_nos_steps closed-form gradient + Adagrad updates of delta
+ * (B x L x hidden, in the workspace) on the final layer only, then the guided reverse step
+ * (_sample_categorical + carry-over).  kl_batch: the B of KLDivLoss(reduction='batchmean')
+ * (models/mdlm.py:254,297) -- pass the GLOBAL per-call batch when a batch is sharded over ranks.
+ * noise: [B][L][vocab] uniforms for noise_mode 2.  probs_out (optional) [B][L][vocab] = guided_probs;
+ * delta_out (optional) [B][L][hidden]; hidden_in (optional) [B][L][hidden]: use this last hidden
+ * state instead of running the blocks.  Absorbing-state + subs parameterisation only. */
+size_t sgpo_nos_workspace_bytes(const sgpo_dit* m, int B, int L);
+int sgpo_nos_denoise(sgpo_dit* m, const int64_t* xt, const float* sigma, int n_sigma, int B, int L,
+                     const float* w_cls, int num_nos_steps, float nos_step_size, float nos_stability_coef,
+                     float move_chance_t, float move_chance_s, int kl_batch, int mask_index, int noise_mode,
+                     const float* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
+                     const float* hidden_in, int64_t* xs_out, float* probs_out, float* delta_out,
+                     void* nos_workspace, size_t nos_workspace_bytes, void* dit_workspace,
+                     size_t dit_workspace_bytes, void* stream);
+
 /* ---- D3PM denoiser: evodiff.model.ByteNetLMTime (third party; call site models/d3pm.py:34-37,
  * hyper-parameters configs/pretrain_model/d3pm.yaml:12-27) -- restated, parity unpinned ----------
  * blob (fp32, device), state_dict order: embedder.embedder.weight, embedder.up_embedder.conv.{weight,bias},

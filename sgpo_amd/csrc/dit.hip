@@ -61,33 +61,7 @@ extern "C" int sgpo_gemm_bf16(const void* A, const void* W, float* C, int M, int
 }
 
 // ------------------------------------------------------------------ model handle
-struct DitBlockW {
-  const float* norm1;
-  const bf16_t* qkv;   // [3H][H]
-  const bf16_t* attn_out;  // [H][H]
-  const float* norm2;
-  const bf16_t* fc1;   // [F][H]
-  const float* fc1_b;
-  const bf16_t* fc2;   // [H][F]
-  const float* fc2_b;
-};
-
-struct sgpo_dit {
-  sgpo_dit_config cfg;
-  float* f32 = nullptr;     // all fp32 parameters (copy of the blob)
-  bf16_t* b16 = nullptr;    // bf16 copies of the GEMM weights
-  float* ada_w = nullptr;   // concatenated adaLN weights [n_mod][cond]
-  float* ada_b = nullptr;   // [n_mod]
-  float* rope_cos = nullptr;
-  float* rope_sin = nullptr;
-  int n_mod = 0;
-  const float* embed;
-  const float *s_w1, *s_b1, *s_w2, *s_b2;
-  std::vector<DitBlockW> blocks;
-  const float* out_norm;
-  const bf16_t* out_lin;    // [vocab][H]
-  const float* out_lin_b;
-};
+#include "dit_model.h"
 
 static size_t dit_block_params(const sgpo_dit_config& c) {
   const size_t H = c.hidden, F = c.mlp_hidden, C = c.cond_dim;
@@ -167,6 +141,7 @@ extern "C" int sgpo_dit_create(const sgpo_dit_config* cfg, const float* blob, si
     HIPF(hipMemcpyAsync(m->ada_b + (size_t)i * 6 * H, ab, 6 * H * sizeof(float), hipMemcpyDeviceToDevice, st));
   }
   m->out_norm = take(H);
+  m->out_lin_f32 = p;
   m->out_lin = take16(V * H, &rc);
   m->out_lin_b = take(V);
   {
@@ -205,6 +180,12 @@ static DitWs dit_carve(const sgpo_dit* m, int B, int L, char* base) {
   w.mod = (float*)carve((size_t)B * m->n_mod * 4);
   w.total = off;
   return w;
+}
+
+// (shift, scale) rows of the final layer's adaLN inside a forward workspace (valid after a forward)
+const float* dit_ws_final_mod(const sgpo_dit* m, int B, int L, void* workspace) {
+  DitWs w = dit_carve(m, B, L, (char*)workspace);
+  return w.mod + (size_t)m->cfg.n_blocks * 6 * m->cfg.hidden;
 }
 
 extern "C" size_t sgpo_dit_workspace_bytes(const sgpo_dit* m, int B, int L) {

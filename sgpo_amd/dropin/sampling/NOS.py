@@ -1,0 +1,39 @@
+"""Drop-in `sampling.NOS.NOS` (reference: sampling/NOS.py:7-48): per reverse step one
+`net._nos_denoise` (backbone once + fused hidden-state optimisation + guided sample)."""
+import torch
+import tqdm
+
+from .base import Algo
+
+
+class NOS(Algo):
+    def __init__(self, net, data_config, forward_op=None, num_nos_steps=1, nos_step_size=0.1, nos_stability_coef=0.01,
+                 n_max_mutations=None, device='cuda'):
+        super().__init__(net=net, forward_op=forward_op, data_config=data_config, n_max_mutations=n_max_mutations,
+                         device=device)
+        self.nos_step_size = nos_step_size
+        self.num_nos_steps = num_nos_steps
+        self.nos_stability_coef = nos_stability_coef
+
+    def update_model(self, classifier):
+        self.forward_op = classifier.eval()
+
+    def project(self, x):
+        return x * self.mask + self.full_seq * (1 - self.mask)
+
+    @torch.no_grad()
+    def inference(self, num_samples=1, verbose=True, detokenize=False, inpaint=False):
+        timesteps = torch.linspace(self.net.timestep - 1, 1, int((self.net.timestep - 1) / 1), dtype=int)
+        timesteps = tqdm.tqdm(timesteps) if verbose else timesteps
+        x = self.net.get_start(num_samples)
+        for t in timesteps:
+            if self.nos_stability_coef is not None:
+                x, _, _ = self.net._nos_denoise(classifier_model=self.forward_op, nos_step_size=self.nos_step_size,
+                                                num_nos_steps=self.num_nos_steps,
+                                                nos_stability_coef=self.nos_stability_coef, xt=x, t=t)
+            else:
+                x = self.net.p_sample(x, t, hard=True)
+        x = self.project(x)
+        if detokenize:
+            return x, self.project_sequences(self._untokenize_batch(x))
+        return x

@@ -105,6 +105,43 @@ class DitDenoiser:
         return (logits, hidden) if return_hidden else logits
 
 
+def nos_denoise(net, xt, w_cls, num_nos_steps, nos_step_size, nos_stability_coef, mt, ms, mask_index, kl_batch=None,
+                sigma=None, noise_src=None, noise=None, want_probs=True, want_delta=False, hidden_in=None):
+    """MDLM._nos_denoise on the GPU (net: DitDenoiser).  Returns (xs, guided_probs | None, delta | None)."""
+    lib = L.load()
+    B, Lq = xt.shape
+    xt = xt.contiguous()
+    dev = net.device
+    w_cls = w_cls.detach().to(dev, torch.float32).reshape(-1).contiguous()
+    assert w_cls.numel() == net.hidden
+    need_d = lib.sgpo_dit_workspace_bytes(net.handle, B, Lq)
+    need_n = lib.sgpo_nos_workspace_bytes(net.handle, B, Lq)
+    if not hasattr(net, 'ws_nos'):
+        net.ws_nos = Workspace(dev)
+    wd, wn = net.ws.get(need_d), net.ws_nos.get(need_n)
+    bd, bn = (wd.data_ptr() + 255) & ~255, (wn.data_ptr() + 255) & ~255
+    if sigma is not None:
+        sigma = sigma.to(dev, torch.float32).reshape(-1).contiguous()
+    if hidden_in is not None:
+        hidden_in = hidden_in.to(dev, torch.float32).contiguous()
+    if noise is not None:
+        noise = noise.to(dev, torch.float32).contiguous()
+        noise_mode = L.NOISE_UNIFORM
+    else:
+        noise_mode = L.NOISE_PHILOX
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    xs = torch.empty_like(xt)
+    probs = torch.empty(B, Lq, net.vocab, dtype=torch.float32, device=dev) if want_probs else None
+    delta = torch.empty(B, Lq, net.hidden, dtype=torch.float32, device=dev) if want_delta else None
+    L.check(lib.sgpo_nos_denoise(net.handle, L.ptr(xt), L.ptr(sigma), 0 if sigma is None else sigma.numel(), B, Lq,
+                                 L.ptr(w_cls), int(num_nos_steps), float(nos_step_size), float(nos_stability_coef),
+                                 float(mt), float(ms), int(kl_batch or B), mask_index, noise_mode, L.ptr(noise), seed,
+                                 off, row_off * Lq, L.ptr(hidden_in), L.ptr(xs), L.ptr(probs), L.ptr(delta),
+                                 C.c_void_p(bn), need_n,
+                                 C.c_void_p(bd), need_d, L.stream_ptr()), 'sgpo_nos_denoise')
+    return xs, probs, delta
+
+
 class MlpValueFunction:
     """MLPModel (problem/protein.py:58-121) on the GPU, incl. the factored jump-ratio kernel."""
 

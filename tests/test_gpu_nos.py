@@ -1,0 +1,94 @@
+"""GPU parity of the NOS step (MDLM._nos_denoise) against the golden captured from the reference
+and against the autograd oracle (delta after the Adagrad steps)."""
+import pytest
+import torch
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+DIM_KEYS = ('hidden', 'cond_dim', 'n_blocks', 'n_heads')
+ALPHABET = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+
+
+@pytest.fixture(scope='module')
+def env():
+    import sgpo_amd
+    sgpo_amd.install_dropin()
+    from sgpo_amd import runtime
+    runtime.init('cuda:0')
+    return runtime
+
+
+def test_nos_denoise_against_reference(env):
+    from models.mdlm import MDLM
+    from oracle import nos as onos
+    from problem.protein_nos import NOSHead
+    from sgpo_amd import weights as W
+    g = load_golden('nos_small')
+    dims = dict(zip(DIM_KEYS, [int(v) for v in g['dims']]))
+    sd = W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
+    cfg = dict(model=dict(hidden_size=dims['hidden'], cond_dim=dims['cond_dim'], n_blocks=dims['n_blocks'],
+                          n_heads=dims['n_heads']))
+    B, Lq = g['x'].shape
+    T = int(g['T'])
+    net = MDLM('synthetic', cfg, None, num_steps=T, seq_len=Lq, device='cuda:0', state_dict=sd)
+    head = NOSHead(dims['hidden'])
+    with torch.no_grad():
+        head.output_layer.weight.copy_(g['w_cls'])
+        head.output_layer.bias.copy_(g['b_cls'])
+    head = head.cuda().eval()
+    for tag in 'abc':
+        t, nsteps, lr, coef = [float(v) for v in g[f'hp_{tag}']]
+        u = g[f'u_{tag}']
+        net.injected_noise.append(u)
+        xs, probs, _ = net._nos_denoise(head, int(nsteps), lr, coef, g['x'].cuda(), torch.tensor(int(t)))
+        p_ref = g[f'probs_{tag}']
+        # the backbone is bf16 on the device: hidden-state error propagates to the probabilities
+        torch.testing.assert_close(probs.cpu(), p_ref, rtol=5e-2, atol=2e-3)
+        v = p_ref / (1e-10 - (u + 1e-10).log())
+        top2 = v.topk(2, dim=-1).values
+        ok = ((top2[..., 0] - top2[..., 1]) > 5e-2 * top2[..., 0]) | (g['x'] != 28)
+        assert ok.float().mean() > 0.8
+        assert torch.equal(xs.cpu()[ok], g[f'xs_{tag}'][ok]), tag
+        assert torch.equal(xs.cpu()[g['x'] != 28], g['x'][g['x'] != 28])      # carry-over
+        # the optimised delta itself against the autograd oracle, fed the oracle's fp32 hidden state so
+        # that only the closed-form backward + Adagrad are compared (fp32 both sides)
+        from oracle import dit as odit
+        from sgpo_amd import runtime as rt
+        _, _, d_ref = onos.nos_denoise(sd, g['w_cls'], g['b_cls'], g['x'], int(t), T, 28, int(nsteps), lr, coef, u)
+        _, hs = odit.dit_forward(sd, g['x'], torch.zeros(B), return_hidden_states=True)
+        mt, ms, _ = net._move_chances(int(t))
+        xs2, p2, d = rt.nos_denoise(net.net, g['x'].cuda(), g['w_cls'], int(nsteps), lr, coef, mt, ms, 28,
+                                    want_delta=True, noise=u, hidden_in=hs[-1])
+        scale = float(d_ref.abs().max())
+        err = float((d.cpu() - d_ref).abs().max()) / scale
+        print(f'nos {tag}: max|delta| {scale:.3e}, rel err vs autograd oracle {err:.3e}')
+        assert err < 2e-3
+        torch.testing.assert_close(p2.cpu(), p_ref, rtol=1e-3, atol=1e-6)
+        assert torch.equal(xs2.cpu()[ok], g[f'xs_{tag}'][ok])
+
+
+def test_nos_sampler_loop(env):
+    from models.mdlm import MDLM
+    from problem.protein_nos import NOSHead
+    from sampling.NOS import NOS
+    from sgpo_amd import weights as W
+    dims = dict(hidden=128, cond_dim=32, n_blocks=2, n_heads=2)
+    sd = W.dit_synthetic_state(seed=2, vocab=31, **dims)
+    cfg = dict(model=dict(hidden_size=128, cond_dim=32, n_blocks=2, n_heads=2))
+    Lq, T = 30, 12
+    net = MDLM('synthetic', cfg, None, num_steps=T, seq_len=Lq, device='cuda:0', state_dict=sd)
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq='M' * Lq, residues=[3, 4, 5, 10, 11, 20])
+    head = NOSHead(128).cuda().eval()
+    algo = NOS(net, dc, forward_op=head, num_nos_steps=3, nos_step_size=0.5, nos_stability_coef=0.1, device='cuda:0')
+    net.reseed(5)
+    x, seqs = algo.inference(num_samples=16, verbose=False, detokenize=True)
+    assert x.shape == (16, Lq) and len(seqs) == 16
+    frozen = [l for l in range(Lq) if l not in algo.residues]
+    assert bool((x[:, frozen] == ALPHABET.index('M')).all())
+    net.reseed(5)
+    assert torch.equal(x, algo.inference(num_samples=16, verbose=False))
+    # unguided branch (nos_stability_coef None -> p_sample hard, NOS.py:34-36)
+    algo.nos_stability_coef = None
+    xu = algo.inference(num_samples=4, verbose=False)
+    assert xu.shape == (4, Lq)

@@ -336,7 +336,41 @@ def gen_daps():
     save('daps_small', **out)
 
 
-GENS = dict(dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps)
+def gen_nos():
+    """MDLM._nos_denoise (models/mdlm.py:184-338) with the reference DITClassifier head
+    (dit.py:420-515, x_emb path: mean-pool + Linear(hidden, 1))."""
+    from models.pretraining.model.mdlm.models.dit import DITClassifier
+    B, L, T = 3, 21, 128
+    net, core, sd = build_ref_mdlm(SMALL, seed=16, L=L, T=T)
+    cm = standins.to_attr(dict(classifier_model=dict(hidden_size=SMALL['hidden'], cond_dim=SMALL['cond_dim'],
+                                                     n_blocks=1, n_heads=SMALL['n_heads'], scale_by_sigma=True,
+                                                     dropout=0.1, pooling='mean')))
+    clf = DITClassifier(cm, vocab_size=31)
+    g = torch.Generator().manual_seed(44)
+    w_cls = torch.randn(1, SMALL['hidden'], generator=g) * 0.5
+    b_cls = torch.randn(1, generator=g)
+    with torch.no_grad():
+        clf.output_layer.weight.copy_(w_cls)
+        clf.output_layer.bias.copy_(b_cls)
+    clf.eval()
+    x = torch.randint(0, 26, (B, L), generator=g)
+    x[:, ::2] = 28
+    x[1, :] = 28
+    out = dict(seed=16, dims=np.array(list(SMALL.values())), T=T, x=x, w_cls=w_cls, b_cls=b_cls)
+    for tag, t, nsteps, lr, coef in (('a', 100, 5, 0.5, 0.1), ('b', 3, 2, 0.5, 10.0), ('c', 64, 5, 0.5, 200.0)):
+        torch.manual_seed(500 + t)
+        u = torch.rand(B, L, 31)
+        torch.manual_seed(500 + t)
+        xs, probs, _ = net._nos_denoise(classifier_model=clf, num_nos_steps=nsteps, nos_step_size=lr,
+                                        nos_stability_coef=coef, xt=x.clone(), t=torch.tensor(t))
+        out[f'xs_{tag}'] = xs
+        out[f'probs_{tag}'] = probs.detach()
+        out[f'u_{tag}'] = u
+        out[f'hp_{tag}'] = np.array([t, nsteps, lr, coef])
+    save('nos_small', **out)
+
+
+GENS = dict(dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
