@@ -42,4 +42,36 @@ struct GemmParams {
   int row_shift;
 };
 
+// Epilogue arithmetic shared by both GEMM kernels (gemm.hip, gemm_p.hip).  Every fused multiply-add is
+// explicit so the two kernels round identically: a batch sharded into pieces small enough for the
+// 128x128 kernel must reproduce the tokens of the unsharded batch bit for bit.
+__device__ __forceinline__ float epi_gelu_tanh(float x) {
+  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))),  tanh(u) = 1 - 2 / (exp(2u) + 1)
+  const float x3 = __fmul_rn(__fmul_rn(x, x), x);
+  const float u = __fmul_rn(0.7978845608028654f, fmaf(0.044715f, x3, x));
+  const float e = __expf(__fmul_rn(2.0f, u));
+  const float t = 1.0f - __fdividef(2.0f, e + 1.0f);
+  return __fmul_rn(__fmul_rn(0.5f, x), 1.0f + t);
+}
+__device__ __forceinline__ float epi_gelu_erf(float x) {
+  return __fmul_rn(__fmul_rn(0.5f, x), 1.0f + erff(__fmul_rn(x, 0.7071067811865476f)));
+}
+__device__ __forceinline__ void epi_rope(float a, float b, float cs, float sn, float& o0, float& o1) {
+  o0 = fmaf(a, cs, -__fmul_rn(b, sn));   // x1 cos - x2 sin
+  o1 = fmaf(a, sn, __fmul_rn(b, cs));    // x1 sin + x2 cos
+}
+__device__ __forceinline__ float epi_gate_res(float acc, float bias, float gate, float xin) {
+  return fmaf(acc + bias, gate, xin);
+}
+
+struct GemmSeg {
+  int n_seg;       // K = n_seg * seg_k ; segment s reads A rows shifted by shift[s]
+  int seg_k;
+  int shift[8];
+};
+
 int launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);
+int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, const int* shifts, hipStream_t stream);
+// persistent 256x128 kernel (gemm_p.hip); returns SGPO_ERR_UNSUPPORTED when the shape does not fit it
+int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, const bf16_t* zero16, hipStream_t stream);
+int gemm_get_zero16(const bf16_t** out);

@@ -1,6 +1,7 @@
 // bf16 MFMA GEMM with fused epilogues -- see gemm.h for the design notes.
 #include "gemm.h"
 #include "prof.h"
+#include <stdlib.h>
 
 #define BM 128
 #define BN 128
@@ -9,12 +10,6 @@
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
-
-struct GemmSeg {
-  int n_seg;       // K = n_seg * seg_k ; segment s reads A rows shifted by shift[s]
-  int seg_k;
-  int shift[8];
-};
 
 __device__ __forceinline__ float gelu_tanh_f(float x) {
   // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
@@ -149,8 +144,8 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
           const int pos = m % p.L;
           const float cs = p.rope_cos[pos * (p.head_dim / 2) + lr];
           const float sn = p.rope_sin[pos * (p.head_dim / 2) + lr];
-          const float o0 = v0 * cs - v1 * sn;
-          const float o1 = v0 * sn + v1 * cs;
+          float o0, o1;
+          epi_rope(v0, v1, cs, sn, o0, o1);
           v0 = o0; v1 = o1;
         }
         C[(size_t)m * p.ldc + na] = f2bf(v0);
@@ -158,21 +153,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
       } else if constexpr (EPI == EPI_BF16 || EPI == EPI_BIAS_GELU || EPI == EPI_BIAS_GELU_ERF) {
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
         if (p.bias) { v0 += p.bias[na]; v1 += p.bias[nb]; }
-        if constexpr (EPI == EPI_BIAS_GELU) { v0 = gelu_tanh_f(v0); v1 = gelu_tanh_f(v1); }
-        if constexpr (EPI == EPI_BIAS_GELU_ERF) { v0 = gelu_erf_f(v0); v1 = gelu_erf_f(v1); }
+        if constexpr (EPI == EPI_BIAS_GELU) { v0 = epi_gelu_tanh(v0); v1 = epi_gelu_tanh(v1); }
+        if constexpr (EPI == EPI_BIAS_GELU_ERF) { v0 = epi_gelu_erf(v0); v1 = epi_gelu_erf(v1); }
         C[(size_t)m * p.ldc + na] = f2bf(v0);
         C[(size_t)m * p.ldc + nb] = f2bf(v1);
       } else if constexpr (EPI == EPI_GATE_RES || EPI == EPI_RES) {
         float* C = reinterpret_cast<float*>(p.C);
-        if (p.bias) { v0 += p.bias[na]; v1 += p.bias[nb]; }
+        const float b0 = p.bias ? p.bias[na] : 0.f, b1 = p.bias ? p.bias[nb] : 0.f;
+        const float x0 = p.xin[(size_t)m * p.ldc + na], x1 = p.xin[(size_t)m * p.ldc + nb];
         if constexpr (EPI == EPI_GATE_RES) {
           int b = m / p.L;
           if (b > p.B - 1) b = p.B - 1;
           const float* g = p.gate + (size_t)b * p.gate_stride;
-          v0 *= g[na]; v1 *= g[nb];
+          C[(size_t)m * p.ldc + na] = epi_gate_res(v0, b0, g[na], x0);
+          C[(size_t)m * p.ldc + nb] = epi_gate_res(v1, b1, g[nb], x1);
+        } else {
+          C[(size_t)m * p.ldc + na] = x0 + (v0 + b0);
+          C[(size_t)m * p.ldc + nb] = x1 + (v1 + b1);
         }
-        C[(size_t)m * p.ldc + na] = p.xin[(size_t)m * p.ldc + na] + v0;
-        C[(size_t)m * p.ldc + nb] = p.xin[(size_t)m * p.ldc + nb] + v1;
       } else {  // EPI_BIAS_F32 / EPI_ACC_F32
         float* C = reinterpret_cast<float*>(p.C);
         if (na < p.N) {
@@ -192,14 +190,14 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
 
 static const bf16_t* g_zero16[16] = {nullptr};
 
-static int get_zero16(const bf16_t** out) {
+int gemm_get_zero16(const bf16_t** out) {
   int dev = 0;
   SGPO_CHECK_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 16) { sgpo_set_error("device index %d out of range", dev); return SGPO_ERR_ARG; }
   if (!g_zero16[dev]) {
     void* z = nullptr;
-    SGPO_CHECK_HIP(hipMalloc(&z, 256));
-    SGPO_CHECK_HIP(hipMemset(z, 0, 256));
+    SGPO_CHECK_HIP(hipMalloc(&z, 16384));  // also serves as an all-zero bias vector (N <= 4096)
+    SGPO_CHECK_HIP(hipMemset(z, 0, 16384));
     g_zero16[dev] = reinterpret_cast<const bf16_t*>(z);
   }
   *out = g_zero16[dev];
@@ -208,7 +206,7 @@ static int get_zero16(const bf16_t** out) {
 
 extern "C" int sgpo_gemm_init_device() {  // called from sgpo_init: allocates the zero page once
   const bf16_t* z;
-  return get_zero16(&z);
+  return gemm_get_zero16(&z);
 }
 
 int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, const int* shifts, hipStream_t stream) {
@@ -223,8 +221,16 @@ int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, con
   sg.n_seg = n_seg; sg.seg_k = seg_k;
   for (int i = 0; i < 8; ++i) sg.shift[i] = (shifts && i < n_seg) ? shifts[i] : 0;
   const bf16_t* z = nullptr;
-  int rc = get_zero16(&z);
+  int rc = gemm_get_zero16(&z);
   if (rc) return rc;
+  {
+    static int use_v1 = -1;
+    if (use_v1 < 0) { const char* e = getenv("SGPO_GEMM"); use_v1 = (e && e[0] == 'v' && e[1] == '1') ? 1 : 0; }
+    if (!use_v1) {
+      rc = launch_gemm_persistent(p, epi, sg, z, stream);
+      if (rc != SGPO_ERR_UNSUPPORTED) return rc;
+    }
+  }
   const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
   dim3 grid(ntm * ntn), block(256);
   const size_t lds = 4 * TILE_BYTES;

@@ -67,7 +67,8 @@ def test_q_sample_d3pm_bit_exact(rt):
     assert torch.equal(out.cpu(), g['q_sample'])
 
 
-@pytest.mark.parametrize('cfg,B,L', [(BN_DEV_SMALL, 3, 20), (dict(), 2, 389)])
+@pytest.mark.parametrize('cfg,B,L', [(BN_DEV_SMALL, 3, 20), (dict(), 2, 389), (BN_DEV_SMALL, 3, 389),
+                                     (dict(n_layers=9), 3, 389)])   # M >= 1024: persistent GEMM + conv taps
 def test_bytenet_forward_vs_oracle(rt, cfg, B, L):
     from oracle import bytenet as obn
     from sgpo_amd import weights as W
