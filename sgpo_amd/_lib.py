@@ -7,7 +7,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'libsgpo_hip.so')
+LIB_PATH = os.environ.get('SGPO_HIP_LIB') or os.path.join(_HERE, 'libsgpo_hip.so')   # override: diagnostic builds only
 
 NOISE_PHILOX, NOISE_EXPONENTIAL, NOISE_UNIFORM, NOISE_NONE = 0, 1, 2, 3
 STEP_SOFT, STEP_SOFT_CG, STEP_HARD = 0, 1, 2

@@ -46,12 +46,11 @@ struct GemmParams {
 // explicit so the two kernels round identically: a batch sharded into pieces small enough for the
 // 128x128 kernel must reproduce the tokens of the unsharded batch bit for bit.
 __device__ __forceinline__ float epi_gelu_tanh(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3))),  tanh(u) = 1 - 2 / (exp(2u) + 1)
-  const float x3 = __fmul_rn(__fmul_rn(x, x), x);
-  const float u = __fmul_rn(0.7978845608028654f, fmaf(0.044715f, x3, x));
-  const float e = __expf(__fmul_rn(2.0f, u));
-  const float t = 1.0f - __fdividef(2.0f, e + 1.0f);
-  return __fmul_rn(__fmul_rn(0.5f, x), 1.0f + t);
+  // 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  2u = 2 sqrt(2/pi) (x + 0.044715 x^3) = x (c0 + c1 x^2);
+  // sigmoid(2u) = 1 / (1 + exp2(x (k0 + k1 x^2))) with k = -c log2(e): 4 VALU + v_exp_f32 + v_rcp_f32
+  const float t = fmaf(-0.10294324f, __fmul_rn(x, x), -2.30220819f);
+  const float e = __builtin_amdgcn_exp2f(__fmul_rn(x, t));
+  return __fmul_rn(x, __builtin_amdgcn_rcpf(1.0f + e));
 }
 __device__ __forceinline__ float epi_gelu_erf(float x) {
   return __fmul_rn(__fmul_rn(0.5f, x), 1.0f + erff(__fmul_rn(x, 0.7071067811865476f)));

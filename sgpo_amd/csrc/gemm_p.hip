@@ -4,40 +4,54 @@
 // Why a second kernel: with K = 512 a tile has only 8 K-steps, so the one-tile-ahead kernel of
 // gemm.hip pays an exposed L2/HBM latency per step and a prologue/epilogue bubble per tile
 // (profiles/r1: 340-505 TFLOP/s).  Here
-//   * one 512-thread workgroup per CU walks its list of 256x128 output tiles (persistent);
-//   * the (tile, k-step) space is FLATTENED into one stream of 64-deep K-steps that flows through a
-//     3-slot LDS ring (48 KiB per slot) filled by LDS-DMA two steps ahead, across tile boundaries,
-//     behind a counted `s_waitcnt vmcnt(6)` and raw `s_barrier`s (never vmcnt(0) inside a tile);
+//   * one 512-thread workgroup per CU walks its list of output tiles (persistent);
+//   * the (tile, k-step) space is FLATTENED into one stream of K-steps that flows through an LDS
+//     ring filled by LDS-DMA D = NST-1 steps ahead, across tile boundaries, behind a counted
+//     `s_waitcnt vmcnt(N)` and raw `s_barrier`s (never vmcnt(0) inside the stream);
 //   * a tile's epilogue runs at the top of the NEXT tile's first step, before that step's prefetch
-//     is issued, so its stores are older than the newest prefetch and the counted wait stays exact;
-//   * residual operands (fp32 x) are prefetched into registers one K-step before they are needed;
+//     is issued.  Its stores sit in the same in-order VM queue as the prefetches, so for the D-1
+//     steps that follow the wait count includes them (exact count: the epilogue of a full tile
+//     issues a compile-time number of store instructions and no loads -- bias and the RoPE table
+//     are copied to LDS once per launch);
 //   * the MFMA is issued "swapped" (A operand = weight rows, B operand = activation rows) so a lane
 //     owns ONE output row and 4 consecutive columns per register quad: epilogues store 8 B (bf16)
 //     or 16 B (fp32) per lane instead of 2-4 B, and RoPE pairs (d, d+32) stay lane-local;
-//   * tiles are dealt so that the N-tiles of one 256-row A panel run on workgroups of one XCD
+//   * tiles are dealt so that the N-tiles of one A row panel run on workgroups of one XCD
 //     (`blockIdx % 8` labels the XCD group): the panel is fetched from HBM once per XCD L2.
-// LDS image and swizzle are those of gemm.hip (lane-linear DMA image, 16-B chunk XOR (row>>1)&7 on
-// the source address and on ds_read_b128: conflict-free).
+// Two tile configurations (the staging traffic per flop, not the MFMA rate, bounds these shapes:
+// PMC shows ~11 B/clk/CU of LDS-DMA at 24 % MFMA utilisation, so the bigger tile wins wherever the
+// epilogue has no fp32 residual tile to carry in registers):
+//   CfgBig 256x256, BK 32, 4-slot ring (128 KiB), waves 2(M) x 4(N), wave tile 128x64
+//   CfgRes 256x128, BK 64, 3-slot ring (144 KiB), waves 4(M) x 2(N), wave tile 64x64; the fp32
+//          residual tile is prefetched into registers one K-step before it is needed.
+// LDS image and swizzle follow gemm.hip (lane-linear DMA image; the 16-B chunk index is XORed with
+// (row>>1)&7 for 128-B rows or (row>>2)&3 for 64-B rows on the source address and on ds_read_b128:
+// conflict-free for the four 16-lane groups of ds_read_b128).
 #include "gemm.h"
 #include "prof.h"
-
-#define PBM 256
-#define PBN 128
-#define PBK 64
-#define NST 3
-#define A_BYTES (PBM * PBK * 2)
-#define B_BYTES (PBN * PBK * 2)
-#define STAGE_BYTES (A_BYTES + B_BYTES)
+#include <stdlib.h>
+#include <type_traits>
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ float gelu_tanh_p(float x) {
-  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  float e = __expf(2.0f * u);
-  return 0.5f * x * (2.0f - 2.0f / (e + 1.0f));
+struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 32, NST = 4; };
+struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NST = 3; };
+
+enum { PF_EXACT = 1 };
+#define LDS_MAX_BYTES 163840
+
+#ifdef SGPO_GEMM_ABLATE   // diagnostic build only (tools/dbg): skip parts of the kernel at run time
+#define ABL(bit) ((dbg & (bit)) != 0)
+#else
+#define ABL(bit) false
+#endif
+
+template <int N>
+__device__ __forceinline__ void wait_vm() {
+  static_assert(N >= 0 && N < 64, "vmcnt is a 6-bit field");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
-__device__ __forceinline__ float gelu_erf_p(float x) { return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f)); }
 
 __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   uint2 r;
@@ -46,20 +60,52 @@ __device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
   return r;
 }
 
-template <int EPI, bool CONV>
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// 4 x 16 B from LDS at addr + 32 i, read and waited for inside one asm statement.  The compiler does not
+// see these as LDS loads, so it does not drain the LDS-DMA queue (vmcnt(0)) in front of them, which it
+// does for any ordinary ds_read it cannot prove disjoint from the DMA image.
+__device__ __forceinline__ void lds_read4x16(f32x4_t (&o)[4], uint32_t addr) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\t"
+      "ds_read_b128 %1, %4 offset:32\n\t"
+      "ds_read_b128 %2, %4 offset:64\n\t"
+      "ds_read_b128 %3, %4 offset:96\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(addr)
+      : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(lptr_t)(p); }
+
+template <int EPI, bool CONV, typename CFG, bool ROPE_LDS>
 __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16, int ntm, int ntn,
-                                                     int grouped) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // NST x (A slot | B slot)
+                                                     int grouped, int flags, int dbg) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NST x (A slot | B slot) | aux tables
+  constexpr int WM = CFG::WM, WN = CFG::WN, MT = CFG::MT, NT = CFG::NT, BK = CFG::BK, NST = CFG::NST;
+  constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
+  constexpr int ROWB = BK * 2, CH = ROWB / 16, RPI = 64 / CH, KK = BK / 16;
+  constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
+  constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192, OPS = A_PW + B_PW, D = NST - 1;
   constexpr bool RES = (EPI == EPI_GATE_RES || EPI == EPI_RES);
+  constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
+  constexpr bool CAN_EXACT = !RES && !F32OUT;       // epilogue = stores only
+  constexpr int E_ST = MT * NT * 4;                 // store instructions per wave in a full-tile epilogue
+  static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
+  static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
+  static_assert(!RES || MT * NT * 4 <= 16, "residual prefetch register budget");
+
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int lr = lane & 31, lh = lane >> 5;
-  const int nk = p.K / PBK;
+  const int nk = p.K / BK;
+  float* auxf = reinterpret_cast<float*>(smem + NST * STAGE);
+  const bool exact = CAN_EXACT && (flags & PF_EXACT) && nk > D;
 
   // ---- this workgroup's tile list
   int t_first, t_stride, n_my, xcd = 0;
-  if (grouped) {  // gridDim.x == 256: XCD group x owns panels x, x+8, ...; 32 workgroups per group
+  if (grouped) {  // gridDim.x == #CU: XCD group x owns panels x, x+8, ...
     xcd = blockIdx.x & 7;
     const int loc = blockIdx.x >> 3, gx = gridDim.x >> 3;
     const int panels = (ntm - xcd + 7) >> 3;
@@ -74,30 +120,42 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   if (n_my == 0) return;
   auto tile_origin = [&](int i, int& m0, int& n0) {
     const int j = t_first + i * t_stride;
-    if (grouped) { m0 = ((j / ntn) * 8 + xcd) * PBM; n0 = (j % ntn) * PBN; }
-    else { m0 = (j / ntn) * PBM; n0 = (j % ntn) * PBN; }
+    if (grouped) { m0 = ((j / ntn) * 8 + xcd) * BM; n0 = (j % ntn) * BN; }
+    else { m0 = (j / ntn) * BM; n0 = (j % ntn) * BN; }
   };
 
-  // ---- LDS-DMA staging of flattened step s = (tile i, k-step kt)
-  auto stage = [&](int s, int slot) {
-    const int i = s / nk, kt = s - i * nk;
-    int m0, n0;
-    tile_origin(i, m0, n0);
-    const int kglob = kt * PBK;
+  // ---- aux tables -> LDS (once per launch; the only ordinary loads outside RES / fp32-out epilogues)
+  if constexpr (!F32OUT) {
+    if constexpr (EPI == EPI_QKV_ROPE) {
+      if constexpr (ROPE_LDS) {
+        const int n = p.L * (p.head_dim / 2);
+        for (int i = tid; i < n; i += 512) { auxf[i] = p.rope_cos[i]; auxf[n + i] = p.rope_sin[i]; }
+      }
+    } else {
+      for (int i = tid; i < p.N; i += 512) auxf[i] = p.bias[i];
+    }
+    __syncthreads();
+  }
+
+  // ---- LDS-DMA staging.  The stream position being staged is tracked incrementally (st_i, st_kt).
+  int st_i = 0, st_kt = 0, st_m0, st_n0;
+  tile_origin(0, st_m0, st_n0);
+  auto stage = [&](int slot) {
+    const int kglob = st_kt * BK;
     int kin = kglob, sh = 0;
     if constexpr (CONV) {
       const int seg = kglob / sg.seg_k;
       kin = kglob - seg * sg.seg_k;
       sh = sg.shift[seg];
     }
-    char* abase = smem + slot * STAGE_BYTES;
+    char* abase = smem + slot * STAGE;
     char* bbase = abase + A_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int ii = wave * 4 + j;
-      const int row = ii * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      int m = m0 + row;
+    for (int j = 0; j < A_PW; ++j) {
+      const int ii = wave * A_PW + j;
+      const int row = ii * RPI + lane / CH;
+      const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+      int m = st_m0 + row;
       if (m > p.M - 1) m = p.M - 1;
       const bf16_t* src = p.A + ((size_t)m + sh) * p.lda + kin + c * 8;
       if constexpr (CONV) {
@@ -107,40 +165,50 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + ii * 1024), 16, 0, 0);
     }
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int ii = wave * 2 + j;
-      const int row = ii * 8 + (lane >> 3);
-      const int c = (lane & 7) ^ ((row >> 1) & 7);
-      int n = n0 + row;
+    for (int j = 0; j < B_PW; ++j) {
+      const int ii = wave * B_PW + j;
+      const int row = ii * RPI + lane / CH;
+      const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+      int n = st_n0 + row;
       if (n > p.N - 1) n = p.N - 1;
       __builtin_amdgcn_global_load_lds((gptr_t)(p.W + (size_t)n * p.ldw + kglob + c * 8), (lptr_t)(bbase + ii * 1024), 16, 0, 0);
     }
+    if (++st_kt == nk) {
+      st_kt = 0;
+      if (++st_i < n_my) tile_origin(st_i, st_m0, st_n0);
+    }
   };
 
-  // fragment offsets inside a slot
-  int x_off[2], w_off[2], x_sw[2], w_sw[2];
+  // ---- fragment addressing inside a slot: the swizzle term is the same for every mt / nt of a lane
+  const int sw = (CH == 8) ? (lr >> 1) & 7 : (lr >> 2) & 3;
+  const int a_lane = (wm * MT * 32 + lr) * ROWB;
+  const int b_lane = A_BYTES + (wn * NT * 32 + lr) * ROWB;
+  int cx[KK];
 #pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int rx = wm * 64 + t * 32 + lr;   // activation row (M)
-    const int rw = wn * 64 + t * 32 + lr;   // weight row (N)
-    x_off[t] = rx * 128; x_sw[t] = (rx >> 1) & 7;
-    w_off[t] = A_BYTES + rw * 128; w_sw[t] = (rw >> 1) & 7;
-  }
+  for (int kk = 0; kk < KK; ++kk) cx[kk] = ((kk * 2 + lh) ^ sw) << 4;
 
-  f32x16 acc[2][2];  // [nt][mt]; D[row = n local][col = m local]
-  float4 res[RES ? 16 : 1];
+  f32x16 acc[NT][MT];  // D[row = n local][col = m local]
+  float4 res[RES ? MT * NT * 4 : 1];
 
-  // ---- epilogue of tile (m0, n0): lane owns rows m(mt) and column quads n = n0 + wn*64 + nt*32 + 8g + 4lh
-  auto epilogue = [&](int m0, int n0) {
+  // ---- epilogue of tile (m0, n0): lane owns rows m(mt) and column quads n = nb0 + nt*32 + 8g + 4lh
+  auto epilogue = [&](int m0, int n0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int nb0 = n0 + wn * NT * 32;
+    if constexpr (EPI == EPI_QKV_ROPE) {
+      static_assert(EPI != EPI_QKV_ROPE || NT == 2, "a wave's 64 columns are one head");
+      const bool rope = nb0 < p.rope_cols;  // wave-uniform
+      const int hd2 = p.head_dim / 2;
+      bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) {
-      const int m = m0 + wm * 64 + mt * 32 + lr;
-      const bool mok = m < p.M;
-      const int nb0 = n0 + wn * 64;
-      if constexpr (EPI == EPI_QKV_ROPE) {
-        const bool rope = nb0 < p.rope_cols;  // wave-uniform: this wave's 64 columns are one head of q or k
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * MT * 32 + mt * 32 + lr;
+        const bool mok = FULL || m < p.M;
         const int pos = (mok ? m : 0) % p.L;
-        bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
+        f32x4_t cs_l[4], sn_l[4];
+        if constexpr (ROPE_LDS) {
+          lds_read4x16(cs_l, lds_addr(auxf + pos * hd2 + 4 * lh));
+          lds_read4x16(sn_l, lds_addr(auxf + (p.L + pos) * hd2 + 4 * lh));
+        }
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = 8 * g + 4 * lh;
@@ -148,8 +216,13 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 #pragma unroll
           for (int q = 0; q < 4; ++q) { a0[q] = acc[0][mt][4 * g + q]; a1[q] = acc[1][mt][4 * g + q]; }
           if (rope) {
-            const float4 cs = *reinterpret_cast<const float4*>(p.rope_cos + pos * (p.head_dim / 2) + d);
-            const float4 sn = *reinterpret_cast<const float4*>(p.rope_sin + pos * (p.head_dim / 2) + d);
+            f32x4_t cs, sn;
+            if constexpr (ROPE_LDS) {
+              cs = cs_l[g]; sn = sn_l[g];
+            } else {
+              cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + pos * hd2 + d);
+              sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + pos * hd2 + d);
+            }
             const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
@@ -163,10 +236,15 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
             *reinterpret_cast<uint2*>(C + (size_t)m * p.ldc + nb0 + 32 + d) = pack4(a1[0], a1[1], a1[2], a1[3]);
           }
         }
-      } else if constexpr (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32) {
-        float* C = reinterpret_cast<float*>(p.C);
+      }
+    } else if constexpr (F32OUT) {
+      float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * MT * 32 + mt * 32 + lr;
+        const bool mok = m < p.M;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
@@ -178,28 +256,32 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
                 C[(size_t)m * p.ldc + n + q] = o;
               }
           }
-      } else {
-        // all small-vector operands first (one wait), then arithmetic and stores
-        float4 bb[8], gg[8];
+      }
+    } else {
+      f32x4_t bb[NT][4];
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+      for (int nt = 0; nt < NT; ++nt) lds_read4x16(bb[nt], lds_addr(auxf + nb0 + nt * 32 + 4 * lh));
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
-            bb[nt * 4 + g] = *reinterpret_cast<const float4*>(p.bias + n);
-            if constexpr (EPI == EPI_GATE_RES) {
-              int b = m / p.L;
-              if (b > p.B - 1) b = p.B - 1;
-              gg[nt * 4 + g] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + n);
-            }
-          }
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m = m0 + wm * MT * 32 + mt * 32 + lr;
+        const bool mok = FULL || m < p.M;
+        float4 gg[EPI == EPI_GATE_RES ? NT * 4 : 1];
+        if constexpr (EPI == EPI_GATE_RES) {
+          int b = m / p.L;
+          if (b > p.B - 1) b = p.B - 1;
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              gg[nt * 4 + g] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 8 * g + 4 * lh);
+        }
         if (mok) {
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt)
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
-              const float4 b4 = bb[nt * 4 + g];
+              const f32x4_t b4 = bb[nt][g];
               float v[4] = {acc[nt][mt][4 * g + 0] + b4.x, acc[nt][mt][4 * g + 1] + b4.y,
                             acc[nt][mt][4 * g + 2] + b4.z, acc[nt][mt][4 * g + 3] + b4.w};
               if constexpr (EPI == EPI_BIAS_GELU) {
@@ -211,7 +293,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
                 for (int q = 0; q < 4; ++q) v[q] = epi_gelu_erf(v[q]);
               }
               if constexpr (RES) {
-                const float4 r = res[(mt * 2 + nt) * 4 + g];
+                const float4 r = res[(mt * NT + nt) * 4 + g];
                 float4 o;
                 if constexpr (EPI == EPI_GATE_RES) {
                   const float4 g4 = gg[nt * 4 + g];   // v already holds acc + bias: fma(acc + bias, gate, xin)
@@ -233,136 +315,207 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   auto load_residual = [&](int m0, int n0) {
     if constexpr (RES) {
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
-        int m = m0 + wm * 64 + mt * 32 + lr;
+      for (int mt = 0; mt < MT; ++mt) {
+        int m = m0 + wm * MT * 32 + mt * 32 + lr;
         if (m > p.M - 1) m = p.M - 1;
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
-            const int n = n0 + wn * 64 + nt * 32 + 8 * g + 4 * lh;
-            res[(mt * 2 + nt) * 4 + g] = *reinterpret_cast<const float4*>(p.xin + (size_t)m * p.ldc + n);
+            const int n = n0 + wn * NT * 32 + nt * 32 + 8 * g + 4 * lh;
+            res[(mt * NT + nt) * 4 + g] = *reinterpret_cast<const float4*>(p.xin + (size_t)m * p.ldc + n);
           }
       }
     }
   };
 
+  auto tile_is_full = [&](int m0, int n0) { return m0 + BM <= p.M && n0 + BN <= p.N; };
+
+  // wait until the stage `ahead` stages behind the newest one has landed; `with_stores` adds the
+  // store instructions of a full-tile epilogue that were issued after it
+  auto wait_stage = [&](int ahead, bool with_stores) {
+    if constexpr (CAN_EXACT) {
+      if (with_stores) {
+        if (ahead >= D - 1) wait_vm<OPS*(D - 1) + E_ST>();
+        else if (D - 1 >= 2 && ahead == 1) wait_vm<OPS + E_ST>();   // only near the end of the stream
+        else wait_vm<E_ST>();
+        return;
+      }
+    }
+    if (ahead >= D - 1) wait_vm<OPS*(D - 1)>();
+    else if (D - 1 >= 2 && ahead == 1) wait_vm<OPS>();
+    else wait_vm<0>();
+  };
+
   const int total = n_my * nk;
-  stage(0, 0);
-  if (total > 1) stage(1, 1);
-  int slot = 0;       // ring slot of step s
-  int kt = 0, ti = 0; // k-step inside the tile, tile index in my list
+#pragma unroll
+  for (int d = 0; d < D; ++d)
+    if (d < total) stage(d);
+  int slot = 0;         // ring slot of step s
+  int kt = 0, ti = 0;   // k-step inside the tile, tile index in my list
+  bool prev_full = false;
   for (int s = 0; s < total; ++s) {
     const bool first_of_tile = (kt == 0);
-    // ---- wait until step s has landed: younger ops = this wave's 6 DMA of step s+1 (none at the very end)
-    if (first_of_tile && ti > 0) {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // also the residual prefetch of the tile just finished
-    } else if (s + 1 < total) {
-      asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
-    } else {
-      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-    }
+    int ahead = total - 1 - s;
+    if (ahead > D - 1) ahead = D - 1;
+    if (RES && first_of_tile && ti > 0) wait_vm<0>();   // also the residual prefetch of the tile just finished
+    else wait_stage(ahead, exact && prev_full && ti > 0 && kt >= 1 && kt <= D - 1);
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
     if (first_of_tile) {
       if (ti > 0) {
         int pm0, pn0;
         tile_origin(ti - 1, pm0, pn0);
-        epilogue(pm0, pn0);   // stores are issued BEFORE the prefetch below: older than it in the vmcnt queue
+        prev_full = tile_is_full(pm0, pn0) && !ABL(4);
+        if (!ABL(4)) {
+          if (prev_full) epilogue(pm0, pn0, std::true_type{});   // stores older than the prefetch below
+          else epilogue(pm0, pn0, std::false_type{});
+        }
+        if (!exact || !prev_full) {
+          // unknown number of epilogue VM operations: only waits that drain them are safe afterwards
+          if constexpr (CAN_EXACT) prev_full = false;
+        }
       }
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < NT; ++a)
 #pragma unroll
-        for (int b = 0; b < 2; ++b)
+        for (int b = 0; b < MT; ++b)
 #pragma unroll
           for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     }
-    if (s + 2 < total) {
-      int ps = slot + 2; if (ps >= NST) ps -= NST;
-      stage(s + 2, ps);
+    if (s + D < total && !ABL(1)) {
+      int ps = slot + D; if (ps >= NST) ps -= NST;
+      stage(ps);
     }
     if (RES && kt == nk - 1) {   // residual tile into registers while the last K-step multiplies
       int m0, n0;
       tile_origin(ti, m0, n0);
       load_residual(m0, n0);
     }
-    const char* base = smem + slot * STAGE_BYTES;
+    const char* base = smem + slot * STAGE;
     __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = kk * 2 + lh;
-      bf16x8 xf[2], wf[2];
+    for (int kk = 0; kk < KK; ++kk) {
+      bf16x8 xf[MT], wf[NT];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        xf[t] = *reinterpret_cast<const bf16x8*>(base + x_off[t] + ((c ^ x_sw[t]) << 4));
-        wf[t] = *reinterpret_cast<const bf16x8*>(base + w_off[t] + ((c ^ w_sw[t]) << 4));
+      for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(base + b_lane + cx[kk] + t * 32 * ROWB);
+#pragma unroll
+      for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(base + a_lane + cx[kk] + t * 32 * ROWB);
+      if (ABL(2)) {
+#pragma unroll
+        for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(wf[t]));
+#pragma unroll
+        for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(xf[t]));
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
       }
-#pragma unroll
-      for (int nt = 0; nt < 2; ++nt)
-#pragma unroll
-        for (int mt = 0; mt < 2; ++mt)
-          acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
     }
     __builtin_amdgcn_s_setprio(0);
     if (++slot == NST) slot = 0;
     if (++kt == nk) { kt = 0; ++ti; }
   }
-  if (RES) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  int pm0, pn0;
-  tile_origin(n_my - 1, pm0, pn0);
-  epilogue(pm0, pn0);
+  if (RES) wait_vm<0>();
+  if (!ABL(4)) {
+    int pm0, pn0;
+    tile_origin(n_my - 1, pm0, pn0);
+    epilogue(pm0, pn0, std::false_type{});
+  }
+}
+
+template <int EPI, typename CFG, bool ROPE_LDS = false>
+static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero16, int n_cu, int dbg, hipStream_t stream) {
+  constexpr int BM = CFG::WM * CFG::MT * 32, BN = CFG::WN * CFG::NT * 32;
+  constexpr int RING = CFG::NST * (BM + BN) * CFG::BK * 2;
+  constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
+  if (q.K % CFG::BK != 0 || sg.seg_k % CFG::BK != 0) return SGPO_ERR_UNSUPPORTED;
+  int flags = PF_EXACT;
+  size_t aux = 0;
+  if (EPI == EPI_QKV_ROPE) {
+    aux = (size_t)q.L * q.head_dim * sizeof(float);   // cos + sin
+    if (!ROPE_LDS) { aux = 0; flags = 0; }           // table read from global: ordinary loads, drained waits
+  } else if (!F32OUT) {
+    aux = (size_t)q.N * sizeof(float);
+  }
+  if (RING + aux > LDS_MAX_BYTES) return SGPO_ERR_UNSUPPORTED;
+  const int ntm = (q.M + BM - 1) / BM, ntn = (q.N + BN - 1) / BN;
+  const int tiles = ntm * ntn;
+  const int grouped = (tiles > n_cu && n_cu % 8 == 0 && ntm >= 8) ? 1 : 0;
+  const int grid = tiles > n_cu ? n_cu : tiles;
+  const size_t lds = RING + ((aux + 15) & ~(size_t)15);
+  static bool attr_set = false;
+  if (!attr_set) {
+    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, false, CFG, ROPE_LDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, true, CFG, ROPE_LDS>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    attr_set = true;
+  }
+  if (sg.n_seg > 1)
+    hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
+  else
+    hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
 }
 
 int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, const bf16_t* zero16, hipStream_t stream) {
   // shapes the vectorised epilogues need; anything else falls back to the generic kernel
-  if (p.K % PBK != 0 || sg.seg_k % PBK != 0) return SGPO_ERR_UNSUPPORTED;
-  if (epi != EPI_BIAS_F32 && epi != EPI_ACC_F32 && (p.N % 64 != 0 || p.ldc % 4 != 0)) return SGPO_ERR_UNSUPPORTED;
+  const bool f32out = (epi == EPI_BIAS_F32 || epi == EPI_ACC_F32);
+  const bool res = (epi == EPI_GATE_RES || epi == EPI_RES);
+  if (!f32out && (p.N % 64 != 0 || p.ldc % 4 != 0)) return SGPO_ERR_UNSUPPORTED;
   if (epi == EPI_QKV_ROPE && (p.head_dim != 64 || p.rope_cols % 64 != 0)) return SGPO_ERR_UNSUPPORTED;
-  if ((epi == EPI_GATE_RES || epi == EPI_RES) && (p.xin == nullptr || (p.gate == nullptr && epi == EPI_GATE_RES))) return SGPO_ERR_UNSUPPORTED;
+  if (res && (p.xin == nullptr || (p.gate == nullptr && epi == EPI_GATE_RES))) return SGPO_ERR_UNSUPPORTED;
   if (p.M < 1024) return SGPO_ERR_UNSUPPORTED;  // tiny problems: the 128x128 kernel fills more CUs
-  const int ntm = (p.M + PBM - 1) / PBM, ntn = (p.N + PBN - 1) / PBN;
-  const int tiles = ntm * ntn;
-  int dev = 0, n_cu = 256;
-  (void)hipGetDevice(&dev);
-  static int cached_cu = 0;
-  if (!cached_cu) { hipDeviceProp_t pr; if (hipGetDeviceProperties(&pr, dev) == hipSuccess) cached_cu = pr.multiProcessorCount; else cached_cu = 256; }
-  n_cu = cached_cu;
-  const int grouped = (tiles > n_cu && n_cu % 8 == 0 && ntm >= 8) ? 1 : 0;
-  const int grid = tiles > n_cu ? n_cu : tiles;
-  const size_t lds = NST * STAGE_BYTES;
-  GemmParams q = p;
-  if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);  // zero page (16 KiB): N <= 4096
-  if (q.N > 4096 && !p.bias) return SGPO_ERR_UNSUPPORTED;
-  const bool conv = sg.n_seg > 1;
-  ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
-#define LAUNCH(E)                                                                                      \
-  case E: {                                                                                            \
-    static bool attr_set = false;                                                                      \
-    if (!attr_set) {                                                                                   \
-      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<E, false>),       \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<E, true>),        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-      attr_set = true;                                                                                 \
-    }                                                                                                  \
-    if (conv)                                                                                          \
-      hipLaunchKernelGGL((gemm_p_kernel<E, true>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped); \
-    else                                                                                               \
-      hipLaunchKernelGGL((gemm_p_kernel<E, false>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped); \
-  } break;
-  switch (epi) {
-    LAUNCH(EPI_BF16)
-    LAUNCH(EPI_QKV_ROPE)
-    LAUNCH(EPI_GATE_RES)
-    LAUNCH(EPI_BIAS_GELU)
-    LAUNCH(EPI_BIAS_F32)
-    LAUNCH(EPI_BIAS_GELU_ERF)
-    LAUNCH(EPI_RES)
-    LAUNCH(EPI_ACC_F32)
-    default:
-      return SGPO_ERR_UNSUPPORTED;
+  if (p.N > 4096) return SGPO_ERR_UNSUPPORTED;   // bias table in LDS beside the ring; zero page (16 KiB) for a null bias
+  if (p.K % 64 != 0 || sg.seg_k % 64 != 0) return SGPO_ERR_UNSUPPORTED;
+  static int n_cu = 0, tile_mode = -1, dbg = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t pr;
+    n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
   }
-#undef LAUNCH
-  SGPO_CHECK_HIP(hipGetLastError());
-  return SGPO_OK;
+  if (tile_mode < 0) {
+    const char* e = getenv("SGPO_GEMM_TILE");   // "s": always the 256x128 tile (A/B measurements)
+    tile_mode = (e && e[0] == 's') ? 1 : 0;
+  }
+#ifdef SGPO_GEMM_ABLATE
+  { const char* e = getenv("SGPO_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+#endif
+  GemmParams q = p;
+  if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
+  const bool big = !res && !f32out && tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096;
+  ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
+  int rc = SGPO_ERR_UNSUPPORTED;
+#define LAUNCH_BOTH(E)                                                              \
+  case E:                                                                           \
+    if (big) rc = launch_cfg<E, CfgBig>(q, sg, zero16, n_cu, dbg, stream);          \
+    if (rc == SGPO_ERR_UNSUPPORTED) rc = launch_cfg<E, CfgRes>(q, sg, zero16, n_cu, dbg, stream); \
+    break;
+#define LAUNCH_RES(E) \
+  case E: rc = launch_cfg<E, CfgRes>(q, sg, zero16, n_cu, dbg, stream); break;
+  switch (epi) {
+    LAUNCH_BOTH(EPI_BF16)
+    case EPI_QKV_ROPE:
+      if (big) {
+        rc = launch_cfg<EPI_QKV_ROPE, CfgBig, true>(q, sg, zero16, n_cu, dbg, stream);
+        if (rc == SGPO_ERR_UNSUPPORTED) rc = launch_cfg<EPI_QKV_ROPE, CfgBig, false>(q, sg, zero16, n_cu, dbg, stream);
+      }
+      if (rc == SGPO_ERR_UNSUPPORTED) rc = launch_cfg<EPI_QKV_ROPE, CfgRes, false>(q, sg, zero16, n_cu, dbg, stream);
+      break;
+    LAUNCH_BOTH(EPI_BIAS_GELU)
+    LAUNCH_BOTH(EPI_BIAS_GELU_ERF)
+    LAUNCH_RES(EPI_GATE_RES)
+    LAUNCH_RES(EPI_RES)
+    LAUNCH_RES(EPI_BIAS_F32)
+    LAUNCH_RES(EPI_ACC_F32)
+    default: break;
+  }
+#undef LAUNCH_BOTH
+#undef LAUNCH_RES
+  return rc;
 }

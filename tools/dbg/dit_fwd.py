@@ -1,0 +1,15 @@
+"""One DiT forward at the bench batch (B x 119 rows) for PMC / kernel-trace runs."""
+import sys, os, torch
+sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '.'))
+from sgpo_amd import runtime as rt, weights as W
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+rt.init('cuda:0')
+net = rt.DitDenoiser(W.dit_synthetic_state(seed=0))
+g = torch.Generator().manual_seed(1)
+x = torch.randint(0, 31, (B, 119), generator=g).cuda()
+sigma = (torch.rand(B, generator=g) * 3).cuda()
+for _ in range(reps):
+    out = net.forward(x, sigma)
+torch.cuda.synchronize()
+print('ok', float(out.float().abs().mean()))
