@@ -34,9 +34,11 @@
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
+typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
+typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 32, NST = 4; };
-struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NST = 3; };
+struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 32, NST = 4, PH = 1; };
+struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NST = 3, PH = 2; };
 
 enum { PF_EXACT = 1 };
 #define LDS_MAX_BYTES 163840
@@ -53,8 +55,8 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-__device__ __forceinline__ uint2 pack4(float a, float b, float c, float d) {
-  uint2 r;
+__device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) {
+  u32x2_t r;
   r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
   r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
   return r;
@@ -76,22 +78,41 @@ __device__ __forceinline__ void lds_read4x16(f32x4_t (&o)[4], uint32_t addr) {
       : "v"(addr)
       : "memory");
 }
+__device__ __forceinline__ void lds_write8(uint32_t addr, u32x2_t v) {
+  asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
+// the wave's earlier ds_writes, then 4 x 16 B at a0, a0 + 1024, a1, a1 + 1024, waited for in the statement
+__device__ __forceinline__ void lds_read_rows(u32x4_t (&o)[4], uint32_t a0, uint32_t a1) {
+  asm volatile(
+      "s_waitcnt lgkmcnt(0)\n\t"
+      "ds_read_b128 %0, %4\n\t"
+      "ds_read_b128 %1, %4 offset:1024\n\t"
+      "ds_read_b128 %2, %5\n\t"
+      "ds_read_b128 %3, %5 offset:1024\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(a0), "v"(a1)
+      : "memory");
+}
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(lptr_t)(p); }
 
 template <int EPI, bool CONV, typename CFG, bool ROPE_LDS>
 __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16, int ntm, int ntn,
-                                                     int grouped, int flags, int dbg) {
+                                                     int grouped, int flags, int skew, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NST x (A slot | B slot) | aux tables
   constexpr int WM = CFG::WM, WN = CFG::WN, MT = CFG::MT, NT = CFG::NT, BK = CFG::BK, NST = CFG::NST;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
   constexpr int ROWB = BK * 2, CH = ROWB / 16, RPI = 64 / CH, KK = BK / 16;
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192, OPS = A_PW + B_PW, D = NST - 1;
+  constexpr int PH = CFG::PH, KP = KK / PH;
   constexpr bool RES = (EPI == EPI_GATE_RES || EPI == EPI_RES);
   constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
-  constexpr bool CAN_EXACT = !RES && !F32OUT;       // epilogue = stores only
-  constexpr int E_ST = MT * NT * 4;                 // store instructions per wave in a full-tile epilogue
+  constexpr bool CAN_EXACT = !F32OUT;   // a full-tile epilogue leaves exactly E_ST stores in flight
+  // store instructions per wave in a full-tile epilogue: bf16 tiles go out as whole 128-B lines (4 per 32 rows)
+  constexpr int E_ST = (RES || F32OUT) ? MT * NT * 4 : MT * 4;
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
+  static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
   static_assert(!RES || MT * NT * 4 <= 16, "residual prefetch register budget");
 
@@ -124,6 +145,15 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     else { m0 = (j / ntn) * BM; n0 = (j % ntn) * BN; }
   };
 
+  // ---- de-phase the workgroups: equal tiles keep all CUs in step, so every CU would store its output
+  // tile in the same few microseconds (an HBM write burst with idle HBM in between).  A start delay of
+  // up to one tile time spreads the epilogues evenly over time.
+  if (skew > 0) {
+    const long long wait = (long long)((blockIdx.x >> 3) & 15) * nk * skew / 16;
+    const long long t0 = __builtin_amdgcn_s_memtime();
+    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
+  }
+
   // ---- aux tables -> LDS (once per launch; the only ordinary loads outside RES / fp32-out epilogues)
   if constexpr (!F32OUT) {
     if constexpr (EPI == EPI_QKV_ROPE) {
@@ -140,38 +170,64 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // ---- LDS-DMA staging.  The stream position being staged is tracked incrementally (st_i, st_kt).
   int st_i = 0, st_kt = 0, st_m0, st_n0;
   tile_origin(0, st_m0, st_n0);
+  // per-lane byte offsets of the DMA pieces inside a full tile (row * ld + swizzled chunk): constant for
+  // the whole launch, so staging a full tile costs one scalar base per operand + OPS DMA instructions
+  uint32_t a_off[A_PW], w_off[B_PW];
+#pragma unroll
+  for (int j = 0; j < A_PW; ++j) {
+    const int row = (wave * A_PW + j) * RPI + lane / CH;
+    const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+    a_off[j] = ((uint32_t)row * (uint32_t)p.lda + c * 8) * 2;
+  }
+#pragma unroll
+  for (int j = 0; j < B_PW; ++j) {
+    const int row = (wave * B_PW + j) * RPI + lane / CH;
+    const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+    w_off[j] = ((uint32_t)row * (uint32_t)p.ldw + c * 8) * 2;
+  }
   auto stage = [&](int slot) {
     const int kglob = st_kt * BK;
-    int kin = kglob, sh = 0;
-    if constexpr (CONV) {
-      const int seg = kglob / sg.seg_k;
-      kin = kglob - seg * sg.seg_k;
-      sh = sg.shift[seg];
-    }
     char* abase = smem + slot * STAGE;
     char* bbase = abase + A_BYTES;
+    if (!CONV && st_m0 + BM <= p.M && st_n0 + BN <= p.N) {
+      const char* ag = reinterpret_cast<const char*>(p.A + (size_t)st_m0 * p.lda + kglob);
+      const char* wg = reinterpret_cast<const char*>(p.W + (size_t)st_n0 * p.ldw + kglob);
 #pragma unroll
-    for (int j = 0; j < A_PW; ++j) {
-      const int ii = wave * A_PW + j;
-      const int row = ii * RPI + lane / CH;
-      const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
-      int m = st_m0 + row;
-      if (m > p.M - 1) m = p.M - 1;
-      const bf16_t* src = p.A + ((size_t)m + sh) * p.lda + kin + c * 8;
+      for (int j = 0; j < A_PW; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(ag + a_off[j]), (lptr_t)(abase + (wave * A_PW + j) * 1024), 16, 0, 0);
+#pragma unroll
+      for (int j = 0; j < B_PW; ++j)
+        __builtin_amdgcn_global_load_lds((gptr_t)(wg + w_off[j]), (lptr_t)(bbase + (wave * B_PW + j) * 1024), 16, 0, 0);
+    } else {
+      int kin = kglob, sh = 0;
       if constexpr (CONV) {
-        const int lp = m % p.L + sh;
-        if (lp < 0 || lp >= p.L) src = zero16;
+        const int seg = kglob / sg.seg_k;
+        kin = kglob - seg * sg.seg_k;
+        sh = sg.shift[seg];
       }
-      __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + ii * 1024), 16, 0, 0);
-    }
 #pragma unroll
-    for (int j = 0; j < B_PW; ++j) {
-      const int ii = wave * B_PW + j;
-      const int row = ii * RPI + lane / CH;
-      const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
-      int n = st_n0 + row;
-      if (n > p.N - 1) n = p.N - 1;
-      __builtin_amdgcn_global_load_lds((gptr_t)(p.W + (size_t)n * p.ldw + kglob + c * 8), (lptr_t)(bbase + ii * 1024), 16, 0, 0);
+      for (int j = 0; j < A_PW; ++j) {
+        const int ii = wave * A_PW + j;
+        const int row = ii * RPI + lane / CH;
+        const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+        int m = st_m0 + row;
+        if (m > p.M - 1) m = p.M - 1;
+        const bf16_t* src = p.A + ((size_t)m + sh) * p.lda + kin + c * 8;
+        if constexpr (CONV) {
+          const int lp = m % p.L + sh;
+          if (lp < 0 || lp >= p.L) src = zero16;
+        }
+        __builtin_amdgcn_global_load_lds((gptr_t)src, (lptr_t)(abase + ii * 1024), 16, 0, 0);
+      }
+#pragma unroll
+      for (int j = 0; j < B_PW; ++j) {
+        const int ii = wave * B_PW + j;
+        const int row = ii * RPI + lane / CH;
+        const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+        int n = st_n0 + row;
+        if (n > p.N - 1) n = p.N - 1;
+        __builtin_amdgcn_global_load_lds((gptr_t)(p.W + (size_t)n * p.ldw + kglob + c * 8), (lptr_t)(bbase + ii * 1024), 16, 0, 0);
+      }
     }
     if (++st_kt == nk) {
       st_kt = 0;
@@ -191,24 +247,55 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   float4 res[RES ? MT * NT * 4 : 1];
 
   // ---- epilogue of tile (m0, n0): lane owns rows m(mt) and column quads n = nb0 + nt*32 + 8g + 4lh
-  auto epilogue = [&](int m0, int n0, auto full_tag) {
+  // bf16 output block of one mt (32 rows x 64 columns, 4 KiB) goes through LDS so that every store
+  // instruction writes 8 whole 128-B lines (lane = 16 B) instead of 8 B in each of 32 lines: the
+  // row-per-lane store tail is bound by store instructions x lines touched, not by bytes.  The block
+  // lives in the pieces of the FREE ring slot that this wave itself fills next (its own LDS-DMA
+  // destinations), so no other wave touches it and no barrier is needed.  Image: row r at
+  // (r & 15) * 128 in half r >> 4; 16-B chunk ch at ch ^ (r & 7); the 8-B halves of a chunk are
+  // swapped when r & 8 (conflict-free ds_write_b64 for the 16-lane groups).
+  auto store_block = [&](const u32x2_t (&pk)[NT][4], int m_blk, int nb0, int fslot, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    char* fs = smem + fslot * STAGE;
+    const uint32_t h0 = lds_addr(fs + (wave * A_PW) * 1024);
+    const uint32_t h1 = (A_PW >= 4) ? h0 + 2048 : lds_addr(fs + A_BYTES + (wave * B_PW) * 1024);
+    const uint32_t wbase = ((lr >> 4) ? h1 : h0) + (lr & 15) * 128 + ((lh ^ ((lr >> 3) & 1)) << 3);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) lds_write8(wbase + (((nt * 4 + g) ^ (lr & 7)) << 4), pk[nt][g]);
+    const int r8 = lane >> 3, c8 = lane & 7;
+    const uint32_t roff = r8 * 128 + ((c8 ^ r8) << 4);
+    u32x4_t o[4];
+    lds_read_rows(o, h0 + roff, h1 + roff);
+    bf16_t* cp = reinterpret_cast<bf16_t*>(p.C) + (size_t)(m_blk + r8) * p.ldc + nb0 + c8 * 8;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u32x4_t v = o[i];
+      if (i & 1) v = u32x4_t{o[i].z, o[i].w, o[i].x, o[i].y};   // rows with bit 3 set hold swapped halves
+      if (FULL || m_blk + i * 8 + r8 < p.M)
+        *reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc) = v;
+    }
+  };
+
+  auto epilogue = [&](int m0, int n0, int fslot, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const int nb0 = n0 + wn * NT * 32;
+    if (!FULL && !F32OUT && nb0 >= p.N) return;   // wave-uniform: this wave's 64 columns lie outside N
     if constexpr (EPI == EPI_QKV_ROPE) {
-      static_assert(EPI != EPI_QKV_ROPE || NT == 2, "a wave's 64 columns are one head");
-      const bool rope = nb0 < p.rope_cols;  // wave-uniform
+      const bool rope = nb0 < p.rope_cols;  // wave-uniform: the 64 columns are one head of q, k or v
       const int hd2 = p.head_dim / 2;
-      bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * MT * 32 + mt * 32 + lr;
-        const bool mok = FULL || m < p.M;
-        const int pos = (mok ? m : 0) % p.L;
+        const int m_blk = m0 + wm * MT * 32 + mt * 32;
+        const int m = m_blk + lr;
+        const int pos = ((FULL || m < p.M) ? m : 0) % p.L;
         f32x4_t cs_l[4], sn_l[4];
         if constexpr (ROPE_LDS) {
           lds_read4x16(cs_l, lds_addr(auxf + pos * hd2 + 4 * lh));
           lds_read4x16(sn_l, lds_addr(auxf + (p.L + pos) * hd2 + 4 * lh));
         }
+        u32x2_t pk[NT][4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           const int d = 8 * g + 4 * lh;
@@ -231,11 +318,11 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
               a0[q] = o0; a1[q] = o1;
             }
           }
-          if (mok) {
-            *reinterpret_cast<uint2*>(C + (size_t)m * p.ldc + nb0 + d) = pack4(a0[0], a0[1], a0[2], a0[3]);
-            *reinterpret_cast<uint2*>(C + (size_t)m * p.ldc + nb0 + 32 + d) = pack4(a1[0], a1[1], a1[2], a1[3]);
-          }
+          pk[0][g] = pack4(a0[0], a0[1], a0[2], a0[3]);
+          pk[1][g] = pack4(a1[0], a1[1], a1[2], a1[3]);
         }
+        store_block(pk, m_blk, nb0, fslot, full_tag);
+        __builtin_amdgcn_sched_barrier(0);   // one block at a time: keeps the epilogue's register peak down
       }
     } else if constexpr (F32OUT) {
       float* C = reinterpret_cast<float*>(p.C);
@@ -263,7 +350,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       for (int nt = 0; nt < NT; ++nt) lds_read4x16(bb[nt], lds_addr(auxf + nb0 + nt * 32 + 4 * lh));
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * MT * 32 + mt * 32 + lr;
+        const int m_blk = m0 + wm * MT * 32 + mt * 32;
+        const int m = m_blk + lr;
         const bool mok = FULL || m < p.M;
         float4 gg[EPI == EPI_GATE_RES ? NT * 4 : 1];
         if constexpr (EPI == EPI_GATE_RES) {
@@ -275,24 +363,25 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
             for (int g = 0; g < 4; ++g)
               gg[nt * 4 + g] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 8 * g + 4 * lh);
         }
-        if (mok) {
+        u32x2_t pk[NT][4];
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
-              const f32x4_t b4 = bb[nt][g];
-              float v[4] = {acc[nt][mt][4 * g + 0] + b4.x, acc[nt][mt][4 * g + 1] + b4.y,
-                            acc[nt][mt][4 * g + 2] + b4.z, acc[nt][mt][4 * g + 3] + b4.w};
-              if constexpr (EPI == EPI_BIAS_GELU) {
+          for (int g = 0; g < 4; ++g) {
+            const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+            const f32x4_t b4 = bb[nt][g];
+            float v[4] = {acc[nt][mt][4 * g + 0] + b4.x, acc[nt][mt][4 * g + 1] + b4.y,
+                          acc[nt][mt][4 * g + 2] + b4.z, acc[nt][mt][4 * g + 3] + b4.w};
+            if constexpr (EPI == EPI_BIAS_GELU) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = epi_gelu_tanh(v[q]);
-              }
-              if constexpr (EPI == EPI_BIAS_GELU_ERF) {
+              for (int q = 0; q < 4; ++q) v[q] = epi_gelu_tanh(v[q]);
+            }
+            if constexpr (EPI == EPI_BIAS_GELU_ERF) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) v[q] = epi_gelu_erf(v[q]);
-              }
-              if constexpr (RES) {
+              for (int q = 0; q < 4; ++q) v[q] = epi_gelu_erf(v[q]);
+            }
+            if constexpr (RES) {
+              if (mok) {
                 const float4 r = res[(mt * NT + nt) * 4 + g];
                 float4 o;
                 if constexpr (EPI == EPI_GATE_RES) {
@@ -302,12 +391,13 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
                   o = make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
                 }
                 *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = o;
-              } else {
-                *reinterpret_cast<uint2*>(reinterpret_cast<bf16_t*>(p.C) + (size_t)m * p.ldc + n) =
-                    pack4(v[0], v[1], v[2], v[3]);
               }
+            } else {
+              pk[nt][g] = pack4(v[0], v[1], v[2], v[3]);
             }
-        }
+          }
+        if constexpr (!RES) store_block(pk, m_blk, nb0, fslot, full_tag);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   };
@@ -331,49 +421,56 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 
   auto tile_is_full = [&](int m0, int n0) { return m0 + BM <= p.M && n0 + BN <= p.N; };
 
-  // wait until the stage `ahead` stages behind the newest one has landed; `with_stores` adds the
-  // store instructions of a full-tile epilogue that were issued after it
-  auto wait_stage = [&](int ahead, bool with_stores) {
-    if constexpr (CAN_EXACT) {
-      if (with_stores) {
-        if (ahead >= D - 1) wait_vm<OPS*(D - 1) + E_ST>();
-        else if (D - 1 >= 2 && ahead == 1) wait_vm<OPS + E_ST>();   // only near the end of the stream
-        else wait_vm<E_ST>();
-        return;
-      }
+  // wait until the stage `ahead` stages behind the newest one has landed; `extra` adds X = MT*NT*4
+  // younger VM operations: the stores of a full-tile epilogue, or the residual prefetch
+  auto wait_stage = [&](int ahead, bool extra) {
+    if (extra) {
+      if (ahead >= D - 1) wait_vm<OPS*(D - 1) + E_ST>();
+      else if (D - 1 >= 2 && ahead == 1) wait_vm<OPS + E_ST>();   // only near the end of the stream
+      else wait_vm<E_ST>();
+      return;
     }
     if (ahead >= D - 1) wait_vm<OPS*(D - 1)>();
     else if (D - 1 >= 2 && ahead == 1) wait_vm<OPS>();
     else wait_vm<0>();
   };
 
+  // ---- main stream.  Each K-step is PH phases; a phase is R (fragment reads; in the first phase
+  // also epilogue, prefetch issue and the wait for the NEXT step's stage) | barrier | M (MFMAs) |
+  // barrier.  Waves w and w+4 share a SIMD; waves 4-7 run one barrier behind waves 0-3, so on every
+  // SIMD one wave's M phase overlaps the other's R phase (ping-pong).  With barriers numbered b0..:
+  // group 0 has R_f before b_2f and M_f after it, group 1 has R_f after b_2f and M_f after b_2f+1.
+  //   RAW: every wave waits for its own DMA of stage s+1 at the end of the last R of step s, i.e.
+  //        before b_2(f+PH)-1 at the latest (f = first phase of step s); the first read of slot s+1
+  //        comes after that barrier.
+  //   WAR: stage(s+D) overwrites the slot of step s-1 in the first R of step s, i.e. after b_2f-1;
+  //        the last reads of that slot were retired (lgkmcnt(0)) before b_2f-1 by both groups.
   const int total = n_my * nk;
+  const int grp = wave >> 2;
 #pragma unroll
   for (int d = 0; d < D; ++d)
     if (d < total) stage(d);
+  {
+    int ahead = total - 1;
+    if (ahead > D - 1) ahead = D - 1;
+    wait_stage(ahead, false);
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+  if (grp == 1) __builtin_amdgcn_s_barrier();
   int slot = 0;         // ring slot of step s
   int kt = 0, ti = 0;   // k-step inside the tile, tile index in my list
   bool prev_full = false;
   for (int s = 0; s < total; ++s) {
-    const bool first_of_tile = (kt == 0);
-    int ahead = total - 1 - s;
-    if (ahead > D - 1) ahead = D - 1;
-    if (RES && first_of_tile && ti > 0) wait_vm<0>();   // also the residual prefetch of the tile just finished
-    else wait_stage(ahead, exact && prev_full && ti > 0 && kt >= 1 && kt <= D - 1);
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
-    if (first_of_tile) {
+    if (kt == 0) {
       if (ti > 0) {
         int pm0, pn0;
         tile_origin(ti - 1, pm0, pn0);
-        prev_full = tile_is_full(pm0, pn0) && !ABL(4);
+        prev_full = exact && tile_is_full(pm0, pn0) && !ABL(4);
         if (!ABL(4)) {
-          if (prev_full) epilogue(pm0, pn0, std::true_type{});   // stores older than the prefetch below
-          else epilogue(pm0, pn0, std::false_type{});
-        }
-        if (!exact || !prev_full) {
-          // unknown number of epilogue VM operations: only waits that drain them are safe afterwards
-          if constexpr (CAN_EXACT) prev_full = false;
+          int fslot = slot + D; if (fslot >= NST) fslot -= NST;   // the slot this step's prefetch fills next
+          if (prev_full) epilogue(pm0, pn0, fslot, std::true_type{});   // stores older than the prefetch below
+          else epilogue(pm0, pn0, fslot, std::false_type{});
         }
       }
 #pragma unroll
@@ -387,42 +484,62 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       int ps = slot + D; if (ps >= NST) ps -= NST;
       stage(ps);
     }
-    if (RES && kt == nk - 1) {   // residual tile into registers while the last K-step multiplies
+    if (RES && kt == nk - 1) {   // residual tile into registers, consumed by the epilogue one step later
       int m0, n0;
       tile_origin(ti, m0, n0);
       load_residual(m0, n0);
     }
     const char* base = smem + slot * STAGE;
-    __builtin_amdgcn_s_setprio(1);
 #pragma unroll
-    for (int kk = 0; kk < KK; ++kk) {
-      bf16x8 xf[MT], wf[NT];
+    for (int ph = 0; ph < PH; ++ph) {
+      bf16x8 xf[KP][MT], wf[KP][NT];
 #pragma unroll
-      for (int t = 0; t < NT; ++t) wf[t] = *reinterpret_cast<const bf16x8*>(base + b_lane + cx[kk] + t * 32 * ROWB);
+      for (int k2 = 0; k2 < KP; ++k2) {
+        const int kk = ph * KP + k2;
 #pragma unroll
-      for (int t = 0; t < MT; ++t) xf[t] = *reinterpret_cast<const bf16x8*>(base + a_lane + cx[kk] + t * 32 * ROWB);
-      if (ABL(2)) {
+        for (int t = 0; t < NT; ++t) wf[k2][t] = *reinterpret_cast<const bf16x8*>(base + b_lane + cx[kk] + t * 32 * ROWB);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(wf[t]));
-#pragma unroll
-        for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(xf[t]));
-      } else {
-#pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[nt], xf[mt], acc[nt][mt], 0, 0, 0);
+        for (int t = 0; t < MT; ++t) xf[k2][t] = *reinterpret_cast<const bf16x8*>(base + a_lane + cx[kk] + t * 32 * ROWB);
       }
+      if (ph == PH - 1 && s + 1 < total) {
+        int ahead = total - 2 - s;
+        if (ahead > D - 1) ahead = D - 1;
+        // younger than stage s+1 besides the stages: the epilogue stores issued at kt = 0 (while
+        // kt <= D-2), or the residual prefetch issued just above
+        const bool ex_st = prev_full && ti > 0 && kt <= D - 2;
+        const bool ex_ld = RES && exact && kt == nk - 1;
+        wait_stage(ahead, ex_st || ex_ld);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int k2 = 0; k2 < KP; ++k2) {
+        if (ABL(2)) {
+#pragma unroll
+          for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(wf[k2][t]));
+#pragma unroll
+          for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(xf[k2][t]));
+        } else {
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][nt], xf[k2][mt], acc[nt][mt], 0, 0, 0);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
-    __builtin_amdgcn_s_setprio(0);
     if (++slot == NST) slot = 0;
     if (++kt == nk) { kt = 0; ++ti; }
   }
-  if (RES) wait_vm<0>();
+  if (grp == 0) __builtin_amdgcn_s_barrier();
   if (!ABL(4)) {
     int pm0, pn0;
     tile_origin(n_my - 1, pm0, pn0);
-    epilogue(pm0, pn0, std::false_type{});
+    epilogue(pm0, pn0, 0, std::false_type{});   // the stream is over: every slot is free
   }
 }
 
@@ -446,6 +563,8 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   const int grouped = (tiles > n_cu && n_cu % 8 == 0 && ntm >= 8) ? 1 : 0;
   const int grid = tiles > n_cu ? n_cu : tiles;
   const size_t lds = RING + ((aux + 15) & ~(size_t)15);
+  static int skew = -1;
+  if (skew < 0) { const char* e = getenv("SGPO_GEMM_SKEW"); skew = e ? atoi(e) : 0; }
   static bool attr_set = false;
   if (!attr_set) {
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, false, CFG, ROPE_LDS>),
@@ -455,9 +574,9 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
     attr_set = true;
   }
   if (sg.n_seg > 1)
-    hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
+    hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, skew, dbg);
   else
-    hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
+    hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, skew, dbg);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
@@ -488,7 +607,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #endif
   GemmParams q = p;
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
-  const bool big = !res && !f32out && tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096;
+  const bool big = !res && !f32out && tile_mode != 1 && p.N % 256 == 0 && p.M >= 4096;
   ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
 #define LAUNCH_BOTH(E)                                                              \
@@ -508,7 +627,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
       if (rc == SGPO_ERR_UNSUPPORTED) rc = launch_cfg<EPI_QKV_ROPE, CfgRes, false>(q, sg, zero16, n_cu, dbg, stream);
       break;
     LAUNCH_BOTH(EPI_BIAS_GELU)
-    LAUNCH_BOTH(EPI_BIAS_GELU_ERF)
+    LAUNCH_RES(EPI_BIAS_GELU_ERF)   // erff needs too many registers beside the 256x256 accumulators
     LAUNCH_RES(EPI_GATE_RES)
     LAUNCH_RES(EPI_RES)
     LAUNCH_RES(EPI_BIAS_F32)
