@@ -116,6 +116,10 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
   static_assert(!RES || MT * NT * 4 <= 16, "residual prefetch register budget");
 
+#ifdef SGPO_PAD   // diagnostic: shift the code placement by SGPO_PAD x 4 bytes
+#pragma unroll
+  for (int i = 0; i < SGPO_PAD; ++i) asm volatile("s_nop 0");
+#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -458,28 +462,29 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     asm volatile("" ::: "memory");
   }
   if (grp == 1) __builtin_amdgcn_s_barrier();
-  int slot = 0;         // ring slot of step s
-  int kt = 0, ti = 0;   // k-step inside the tile, tile index in my list
+  int slot = 0;   // ring slot of step s
+  int s = 0;      // position in the flattened (tile, k-step) stream
   bool prev_full = false;
-  for (int s = 0; s < total; ++s) {
-    if (kt == 0) {
-      if (ti > 0) {
-        int pm0, pn0;
-        tile_origin(ti - 1, pm0, pn0);
-        prev_full = exact && tile_is_full(pm0, pn0) && !ABL(4);
-        if (!ABL(4)) {
-          int fslot = slot + D; if (fslot >= NST) fslot -= NST;   // the slot this step's prefetch fills next
-          if (prev_full) epilogue(pm0, pn0, fslot, std::true_type{});   // stores older than the prefetch below
-          else epilogue(pm0, pn0, fslot, std::false_type{});
-        }
+  // (tile loop around a k loop rather than one flat loop with a conditional epilogue: the register
+  //  allocator then keeps the accumulators in place instead of shuffling them every step)
+  for (int ti = 0; ti < n_my; ++ti) {
+    if (ti > 0) {
+      int pm0, pn0;
+      tile_origin(ti - 1, pm0, pn0);
+      prev_full = exact && tile_is_full(pm0, pn0) && !ABL(4);
+      if (!ABL(4)) {
+        int fslot = slot + D; if (fslot >= NST) fslot -= NST;   // the slot this step's prefetch fills next
+        if (prev_full) epilogue(pm0, pn0, fslot, std::true_type{});   // stores older than the prefetch below
+        else epilogue(pm0, pn0, fslot, std::false_type{});
       }
-#pragma unroll
-      for (int a = 0; a < NT; ++a)
-#pragma unroll
-        for (int b = 0; b < MT; ++b)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
     }
+#pragma unroll
+    for (int a = 0; a < NT; ++a)
+#pragma unroll
+      for (int b = 0; b < MT; ++b)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+   for (int kt = 0; kt < nk; ++kt, ++s) {
     if (s + D < total && !ABL(1)) {
       int ps = slot + D; if (ps >= NST) ps -= NST;
       stage(ps);
@@ -533,7 +538,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       asm volatile("" ::: "memory");
     }
     if (++slot == NST) slot = 0;
-    if (++kt == nk) { kt = 0; ++ti; }
+   }
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
   if (!ABL(4)) {
