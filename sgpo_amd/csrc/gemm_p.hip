@@ -467,8 +467,14 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   bool prev_full = false;
   // (tile loop around a k loop rather than one flat loop with a conditional epilogue: the register
   //  allocator then keeps the accumulators in place instead of shuffling them every step)
+  // Epilogue placement: group 0 runs a tile's epilogue at the top of the next tile's first R phase;
+  // group 1 (EARLY1) runs it at the end of the tile's last M phase, which is the SAME barrier interval,
+  // so the two waves of a SIMD share the VALU for their epilogues instead of running them one after
+  // the other.  Both orders put the stores between stage(e+D) and stage(e+1+D) in the wave's VM queue
+  // (e = last step of the tile), so the wait counts below are the same for both groups.
+  constexpr bool EARLY1 = !RES && !F32OUT;
   for (int ti = 0; ti < n_my; ++ti) {
-    if (ti > 0) {
+    if (ti > 0 && !(EARLY1 && grp == 1)) {
       int pm0, pn0;
       tile_origin(ti - 1, pm0, pn0);
       prev_full = exact && tile_is_full(pm0, pn0) && !ABL(4);
@@ -484,12 +490,13 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       for (int b = 0; b < MT; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-   for (int kt = 0; kt < nk; ++kt, ++s) {
+   auto step = [&](int kt, auto last_tag) {
+    constexpr bool LAST = decltype(last_tag)::value;   // the tile's last k-step (peeled out of the loop)
     if (s + D < total && !ABL(1)) {
       int ps = slot + D; if (ps >= NST) ps -= NST;
       stage(ps);
     }
-    if (RES && kt == nk - 1) {   // residual tile into registers, consumed by the epilogue one step later
+    if (RES && LAST) {   // residual tile into registers, consumed by the epilogue one step later
       int m0, n0;
       tile_origin(ti, m0, n0);
       load_residual(m0, n0);
@@ -512,7 +519,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         // younger than stage s+1 besides the stages: the epilogue stores issued at kt = 0 (while
         // kt <= D-2), or the residual prefetch issued just above
         const bool ex_st = prev_full && ti > 0 && kt <= D - 2;
-        const bool ex_ld = RES && exact && kt == nk - 1;
+        const bool ex_ld = RES && exact && LAST;
         wait_stage(ahead, ex_st || ex_ld);
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -534,14 +541,28 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (EARLY1 && LAST && grp == 1 && ph == PH - 1) {
+        int tm0, tn0;
+        tile_origin(ti, tm0, tn0);
+        prev_full = exact && tile_is_full(tm0, tn0) && !ABL(4);
+        if (!ABL(4)) {
+          // free slot = this step's own: every read of it was retired before this M phase began
+          if (prev_full) epilogue(tm0, tn0, slot, std::true_type{});
+          else epilogue(tm0, tn0, slot, std::false_type{});
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
     if (++slot == NST) slot = 0;
-   }
+    ++s;
+   };
+   for (int kt = 0; kt < nk - 1; ++kt) step(kt, std::false_type{});
+   step(nk - 1, std::true_type{});
   }
   if (grp == 0) __builtin_amdgcn_s_barrier();
-  if (!ABL(4)) {
+  if (!ABL(4) && !(EARLY1 && grp == 1)) {
     int pm0, pn0;
     tile_origin(n_my - 1, pm0, pn0);
     epilogue(pm0, pn0, 0, std::false_type{});   // the stream is over: every slot is free
