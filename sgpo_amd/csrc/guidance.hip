@@ -235,6 +235,11 @@ __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restric
   const int s = lane & 31, h = lane >> 5;
   const int n_waves = gridDim.x * 4;
   for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
+    // The 192 weight fragments are the same for every tile; hoisted out of this loop they would need
+    // 192 VGPRs and spill to scratch.  An opaque (always zero) offset keeps the LDS reads inside.
+    int wofs = 0;
+    asm volatile("" : "+s"(wofs));
+    const float* wt = wl + wofs;
     const int b = tile / n_read, i = tile % n_read;
     int xi = (int)x[(size_t)b * L + read_pos[i]];
     xi = xi < 0 ? 0 : (xi >= alphabet ? alphabet - 1 : xi);
@@ -258,19 +263,19 @@ __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restric
         a[t][g * 4 + 3] = fmaxf(same ? p4.w : (p4.w + n4.w - o4.w), 0.f);
       }
     // mlp.2 + ReLU
-    mfma_layer(wl, a, o, lane);
+    mfma_layer(wt, a, o, lane);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) o[t][r] = fmaxf(o[t][r] + bl[0 * MH + (t * 16 + r) * 2 + h], 0.f);
     // mlp.4 (no activation)
-    mfma_layer(wl + MH * MH, o, a, lane);
+    mfma_layer(wt + MH * MH, o, a, lane);
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int r = 0; r < 16; ++r) a[t][r] = a[t][r] + bl[1 * MH + (t * 16 + r) * 2 + h];
     // cls_head.0 + ReLU
-    mfma_layer(wl + 2 * MH * MH, a, o, lane);
+    mfma_layer(wt + 2 * MH * MH, a, o, lane);
     float f = 0.f;
 #pragma unroll
     for (int t = 0; t < 2; ++t)
