@@ -82,6 +82,23 @@ def cpu_baseline(sd, msd, n_seq=8, n_steps=48):
                        f'{dt:.1f} s measured, scaled linearly to 127 steps')
 
 
+def pmc_traffic(kernel, batch):
+    import glob
+    if batch != 4096:        # the PMC passes were taken at the default bench batch
+        return None
+    files = sorted(glob.glob(os.path.join(ROOT, 'profiles', '*', '*_pmc_traffic.json')))
+    for f in reversed(files):
+        try:
+            d = json.load(open(f))
+        except (OSError, ValueError):
+            continue
+        if kernel in d:
+            e = d[kernel]
+            return dict(hbm_bytes_per_launch=e['hbm_bytes'], fetch_bytes=e['fetch_bytes'], write_bytes=e['write_bytes'],
+                        l2_hit=round(e['l2_hit'], 3), source=os.path.relpath(f, ROOT))
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -176,6 +193,12 @@ def main():
             roof = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
                         frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(avg_s * 1e6, 2),
                         bytes_per_launch=per_launch)
+        # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the
+        # per-launch figure comes from the committed rocprofv3 --pmc summary of the same kernel at the same
+        # shape (profiles/<round>/*_pmc_traffic.json, written by tools/dbg/pmc_run.sh + pmc_agg.py); null if absent
+        tr = pmc_traffic(name, B)
+        roof['traffic'] = tr['hbm_bytes_per_launch'] if tr else None    # bytes per launch
+        roof['traffic_detail'] = tr
         # whole-denoiser MFMA utilisation (all GEMM + attention flops over their summed time)
         gf = sum(work[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
         gt = sum(ms[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
