@@ -78,6 +78,18 @@ __device__ __forceinline__ void lds_read4x16(f32x4_t (&o)[4], uint32_t addr) {
       : "v"(addr)
       : "memory");
 }
+// same with four separate addresses (swizzled table rows)
+__device__ __forceinline__ void lds_read4(f32x4_t (&o)[4], uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3) {
+  asm volatile(
+      "ds_read_b128 %0, %4\n\t"
+      "ds_read_b128 %1, %5\n\t"
+      "ds_read_b128 %2, %6\n\t"
+      "ds_read_b128 %3, %7\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3])
+      : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
+      : "memory");
+}
 __device__ __forceinline__ void lds_write8(uint32_t addr, u32x2_t v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -98,7 +110,7 @@ __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(
 
 template <int EPI, bool CONV, typename CFG, bool ROPE_LDS>
 __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16, int ntm, int ntn,
-                                                     int grouped, int flags, int skew, int dbg) {
+                                                     int grouped, int flags, int dbg) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NST x (A slot | B slot) | aux tables
   constexpr int WM = CFG::WM, WN = CFG::WN, MT = CFG::MT, NT = CFG::NT, BK = CFG::BK, NST = CFG::NST;
   constexpr int BM = WM * MT * 32, BN = WN * NT * 32;
@@ -116,10 +128,6 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
   static_assert(!RES || MT * NT * 4 <= 16, "residual prefetch register budget");
 
-#ifdef SGPO_PAD   // diagnostic: shift the code placement by SGPO_PAD x 4 bytes
-#pragma unroll
-  for (int i = 0; i < SGPO_PAD; ++i) asm volatile("s_nop 0");
-#endif
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
@@ -149,21 +157,18 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     else { m0 = (j / ntn) * BM; n0 = (j % ntn) * BN; }
   };
 
-  // ---- de-phase the workgroups: equal tiles keep all CUs in step, so every CU would store its output
-  // tile in the same few microseconds (an HBM write burst with idle HBM in between).  A start delay of
-  // up to one tile time spreads the epilogues evenly over time.
-  if (skew > 0) {
-    const long long wait = (long long)((blockIdx.x >> 3) & 15) * nk * skew / 16;
-    const long long t0 = __builtin_amdgcn_s_memtime();
-    while ((long long)__builtin_amdgcn_s_memtime() - t0 < wait) __builtin_amdgcn_s_sleep(16);
-  }
-
   // ---- aux tables -> LDS (once per launch; the only ordinary loads outside RES / fp32-out epilogues)
   if constexpr (!F32OUT) {
     if constexpr (EPI == EPI_QKV_ROPE) {
       if constexpr (ROPE_LDS) {
         const int n = p.L * (p.head_dim / 2);
-        for (int i = tid; i < n; i += 512) { auxf[i] = p.rope_cos[i]; auxf[n + i] = p.rope_sin[i]; }
+        // rows of 32 floats (head_dim 64); lanes read rows of consecutive positions at the same column,
+        // so the 16-B chunk index is XORed with (pos >> 1) & 7: conflict-free for ds_read_b128
+        for (int i = tid; i < n; i += 512) {
+          const int pos = i >> 5, j = ((((i >> 2) & 7) ^ ((pos >> 1) & 7)) << 2) | (i & 3);
+          auxf[pos * 32 + j] = p.rope_cos[i];
+          auxf[n + pos * 32 + j] = p.rope_sin[i];
+        }
       }
     } else {
       for (int i = tid; i < p.N; i += 512) auxf[i] = p.bias[i];
@@ -296,8 +301,11 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         const int pos = ((FULL || m < p.M) ? m : 0) % p.L;
         f32x4_t cs_l[4], sn_l[4];
         if constexpr (ROPE_LDS) {
-          lds_read4x16(cs_l, lds_addr(auxf + pos * hd2 + 4 * lh));
-          lds_read4x16(sn_l, lds_addr(auxf + (p.L + pos) * hd2 + 4 * lh));
+          const uint32_t rb = lds_addr(auxf + pos * 32), key = (pos >> 1) & 7, sb = (uint32_t)p.L * 128;
+          const uint32_t c0 = ((lh + 0) ^ key) << 4, c1 = ((lh + 2) ^ key) << 4, c2 = ((lh + 4) ^ key) << 4,
+                         c3 = ((lh + 6) ^ key) << 4;
+          lds_read4(cs_l, rb + c0, rb + c1, rb + c2, rb + c3);
+          lds_read4(sn_l, rb + sb + c0, rb + sb + c1, rb + sb + c2, rb + sb + c3);
         }
         u32x2_t pk[NT][4];
 #pragma unroll
@@ -589,8 +597,6 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   const int grouped = (tiles > n_cu && n_cu % 8 == 0 && ntm >= 8) ? 1 : 0;
   const int grid = tiles > n_cu ? n_cu : tiles;
   const size_t lds = RING + ((aux + 15) & ~(size_t)15);
-  static int skew = -1;
-  if (skew < 0) { const char* e = getenv("SGPO_GEMM_SKEW"); skew = e ? atoi(e) : 0; }
   static bool attr_set = false;
   if (!attr_set) {
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, false, CFG, ROPE_LDS>),
@@ -600,9 +606,9 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
     attr_set = true;
   }
   if (sg.n_seg > 1)
-    hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, skew, dbg);
+    hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
   else
-    hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, skew, dbg);
+    hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
