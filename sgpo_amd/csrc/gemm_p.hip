@@ -21,7 +21,9 @@
 // Two tile configurations (the staging traffic per flop, not the MFMA rate, bounds these shapes:
 // PMC shows ~11 B/clk/CU of LDS-DMA at 24 % MFMA utilisation, so the bigger tile wins wherever the
 // epilogue has no fp32 residual tile to carry in registers):
-//   CfgBig 256x256, BK 32, 4-slot ring (128 KiB), waves 2(M) x 4(N), wave tile 128x64
+//   CfgBig 256x256, BK 64, 2-slot ring (128 KiB), waves 2(M) x 4(N), wave tile 128x64 (BK 32 with a
+//          4-slot ring measured 5 % slower: its 64-B rows make twice the L2 requests per DMA piece,
+//          ~175 instead of ~105 cycles of issue time per piece)
 //   CfgRes 256x128, BK 64, 3-slot ring (144 KiB), waves 4(M) x 2(N), wave tile 64x64; the fp32
 //          residual tile is prefetched into registers one K-step before it is needed.
 // LDS image and swizzle follow gemm.hip (lane-linear DMA image; the 16-B chunk index is XORed with
@@ -37,7 +39,7 @@ typedef __attribute__((address_space(3))) void* lptr_t;
 typedef uint32_t u32x2_t __attribute__((ext_vector_type(2)));
 typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
-struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 32, NST = 4, PH = 1; };
+struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
 struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NST = 3, PH = 2; };
 
 enum { PF_EXACT = 1 };
@@ -47,6 +49,21 @@ enum { PF_EXACT = 1 };
 #define ABL(bit) ((dbg & (bit)) != 0)
 #else
 #define ABL(bit) false
+#endif
+
+#ifdef SGPO_GEMM_STAMP   // diagnostic build only (tools/dbg/gemm_stamps.py): per-wave cycle totals by loop section
+__device__ unsigned long long g_stamps[1024 * 8 * 8];
+#define STAMP_DECL unsigned long long st_acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long st_t = __builtin_amdgcn_s_memtime();
+#define STAMP(i) do { const unsigned long long st_n = __builtin_amdgcn_s_memtime(); st_acc[i] += st_n - st_t; st_t = st_n; } while (0)
+#define STAMP_TAKE(v) const unsigned long long v = __builtin_amdgcn_s_memtime()
+#define STAMP_PUT(i, v) do { st_acc[i] += (v) - st_t; st_t = (v); } while (0)
+#define STAMP_FLUSH do { if ((dbg & 8) && lane == 0) for (int i = 0; i < 8; ++i) g_stamps[(blockIdx.x * 8 + wave) * 8 + i] = st_acc[i]; } while (0)
+#else
+#define STAMP_DECL
+#define STAMP(i)
+#define STAMP_TAKE(v)
+#define STAMP_PUT(i, v)
+#define STAMP_FLUSH
 #endif
 
 template <int N>
@@ -470,6 +487,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     asm volatile("" ::: "memory");
   }
   if (grp == 1) __builtin_amdgcn_s_barrier();
+  STAMP_DECL
   int slot = 0;   // ring slot of step s
   int s = 0;      // position in the flattened (tile, k-step) stream
   bool prev_full = false;
@@ -482,6 +500,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // (e = last step of the tile), so the wait counts below are the same for both groups.
   constexpr bool EARLY1 = !RES && !F32OUT;
   for (int ti = 0; ti < n_my; ++ti) {
+    STAMP(7);
     if (ti > 0 && !(EARLY1 && grp == 1)) {
       int pm0, pn0;
       tile_origin(ti - 1, pm0, pn0);
@@ -498,12 +517,15 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       for (int b = 0; b < MT; ++b)
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+   STAMP(5);
    auto step = [&](int kt, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;   // the tile's last k-step (peeled out of the loop)
+    STAMP(7);
     if (s + D < total && !ABL(1)) {
       int ps = slot + D; if (ps >= NST) ps -= NST;
       stage(ps);
     }
+    STAMP(0);
     if (RES && LAST) {   // residual tile into registers, consumed by the epilogue one step later
       int m0, n0;
       tile_origin(ti, m0, n0);
@@ -530,8 +552,12 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         const bool ex_ld = RES && exact && LAST;
         wait_stage(ahead, ex_st || ex_ld);
       }
+      STAMP_TAKE(st_a);
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      STAMP_PUT(1, st_a);
+      STAMP(2);
       __builtin_amdgcn_s_barrier();
+      STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int k2 = 0; k2 < KP; ++k2) {
@@ -549,6 +575,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         }
       }
       __builtin_amdgcn_sched_barrier(0);
+      STAMP(4);
       if (EARLY1 && LAST && grp == 1 && ph == PH - 1) {
         int tm0, tn0;
         tile_origin(ti, tm0, tn0);
@@ -559,8 +586,10 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
           else epilogue(tm0, tn0, slot, std::false_type{});
         }
         __builtin_amdgcn_sched_barrier(0);
+        STAMP(5);
       }
       __builtin_amdgcn_s_barrier();
+      STAMP(6);
       asm volatile("" ::: "memory");
     }
     if (++slot == NST) slot = 0;
@@ -575,7 +604,17 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     tile_origin(n_my - 1, pm0, pn0);
     epilogue(pm0, pn0, 0, std::false_type{});   // the stream is over: every slot is free
   }
+  STAMP(5);
+  STAMP_FLUSH;
 }
+
+#ifdef SGPO_GEMM_STAMP
+extern "C" int sgpo_gemm_stamps_read(unsigned long long* out, int n) {
+  SGPO_CHECK_HIP(hipDeviceSynchronize());
+  SGPO_CHECK_HIP(hipMemcpyFromSymbol(out, HIP_SYMBOL(g_stamps), (size_t)n * sizeof(unsigned long long)));
+  return SGPO_OK;
+}
+#endif
 
 template <int EPI, typename CFG, bool ROPE_LDS = false>
 static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero16, int n_cu, int dbg, hipStream_t stream) {
@@ -637,9 +676,12 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #ifdef SGPO_GEMM_ABLATE
   { const char* e = getenv("SGPO_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
 #endif
+#ifdef SGPO_GEMM_STAMP
+  { const char* e = getenv("SGPO_GEMM_STAMP_EPI"); dbg = (e && atoi(e) == epi) ? 8 : 0; }
+#endif
   GemmParams q = p;
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
-  const bool big = !res && !f32out && tile_mode != 1 && p.N % 256 == 0 && p.M >= 4096;
+  const bool big = !res && !f32out && tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096;
   ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
 #define LAUNCH_BOTH(E)                                                              \
