@@ -59,8 +59,12 @@ __device__ __forceinline__ void epi_rope(float a, float b, float cs, float sn, f
   o0 = fmaf(a, cs, -__fmul_rn(b, sn));   // x1 cos - x2 sin
   o1 = fmaf(a, sn, __fmul_rn(b, cs));    // x1 sin + x2 cos
 }
+// x + gate * (acc + bias), the product rounded before the add (two roundings, never contracted to an
+// fma): the 256x256 kernel forms the product in the accumulator layout and adds x after a transpose
+// through LDS, and both kernels must give the same bits.  (The reference rounds the product to bf16.)
+__device__ __forceinline__ float epi_gate_mul(float acc, float bias, float gate) { return __fmul_rn(acc + bias, gate); }
 __device__ __forceinline__ float epi_gate_res(float acc, float bias, float gate, float xin) {
-  return fmaf(acc + bias, gate, xin);
+  return __fadd_rn(xin, epi_gate_mul(acc, bias, gate));
 }
 
 struct GemmSeg {

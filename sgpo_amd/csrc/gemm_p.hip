@@ -107,6 +107,9 @@ __device__ __forceinline__ void lds_read4(f32x4_t (&o)[4], uint32_t a0, uint32_t
       : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
       : "memory");
 }
+__device__ __forceinline__ void lds_write16(uint32_t addr, f32x4_t v) {
+  asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
+}
 __device__ __forceinline__ void lds_write8(uint32_t addr, u32x2_t v) {
   asm volatile("ds_write_b64 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -139,11 +142,14 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
   constexpr bool CAN_EXACT = !F32OUT;   // a full-tile epilogue leaves exactly E_ST stores in flight
   // store instructions per wave in a full-tile epilogue: bf16 tiles go out as whole 128-B lines (4 per 32 rows)
-  constexpr int E_ST = (RES || F32OUT) ? MT * NT * 4 : MT * 4;
+  // PRE: the fp32 residual tile fits in 16 float4 registers and is prefetched one K-step ahead (CfgRes);
+  // otherwise (CfgBig) the residual is loaded inside the epilogue, block by block, in whole lines
+  constexpr bool PRE = RES && MT * NT * 4 <= 16;
+  constexpr int E_ST = (PRE || F32OUT) ? MT * NT * 4 : RES ? MT * 8 : MT * 4;
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
   static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
-  static_assert(!RES || MT * NT * 4 <= 16, "residual prefetch register budget");
+  static_assert(!RES || PRE || (A_PW >= 4 && B_PW >= 4), "fp32 output staging: 32 x 64 block = two 4-KiB halves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -270,7 +276,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   for (int kk = 0; kk < KK; ++kk) cx[kk] = ((kk * 2 + lh) ^ sw) << 4;
 
   f32x16 acc[NT][MT];  // D[row = n local][col = m local]
-  float4 res[RES ? MT * NT * 4 : 1];
+  float4 res[PRE ? MT * NT * 4 : 1];
 
   // ---- epilogue of tile (m0, n0): lane owns rows m(mt) and column quads n = nb0 + nt*32 + 8g + 4lh
   // bf16 output block of one mt (32 rows x 64 columns, 4 KiB) goes through LDS so that every store
@@ -301,6 +307,39 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       if (i & 1) v = u32x4_t{o[i].z, o[i].w, o[i].x, o[i].y};   // rows with bit 3 set hold swapped halves
       if (FULL || m_blk + i * 8 + r8 < p.M)
         *reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc) = v;
+    }
+  };
+
+  // fp32 residual epilogue of the 256x256 tile, one mt block (32 rows x 64 columns, 8 KiB) at a time:
+  // y = gate * (acc + bias) goes through the wave's own pieces of the free slot (as store_block does) and
+  // comes back one 16-B chunk per lane, 4 whole 256-B rows per instruction; the residual x is loaded
+  // and x + y stored in that layout, so every global access is a run of whole lines.  Image: row r at
+  // (r & 15) * 256 in half r >> 4, 16-B chunk c at c ^ (r & 7).
+  auto res_block = [&](int m_blk, int nb0, uint32_t h0, uint32_t h1, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    const int r4 = lane >> 4, c16 = lane & 15;
+    const float* xp = p.xin + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
+    float* cp = reinterpret_cast<float*>(p.C) + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
+    f32x4_t xr[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      size_t ro = (size_t)(i * 4) * p.ldc;
+      if (!FULL && m_blk + i * 4 + r4 > p.M - 1) ro = 0;   // any valid row: the value is not stored
+      xr[i] = *reinterpret_cast<const f32x4_t*>(xp + ro);
+    }
+    const uint32_t k0 = r4 * 256 + ((c16 ^ r4) << 4), k1 = r4 * 256 + ((c16 ^ (r4 + 4)) << 4);
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+      const uint32_t hb = hf ? h1 : h0;
+      f32x4_t o[4];
+      lds_read4(o, hb + k0, hb + 1024 + k1, hb + 2048 + k0, hb + 3072 + k1);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int i = hf * 4 + j;
+        const f32x4_t x4 = xr[i];
+        const f32x4_t v = {__fadd_rn(x4.x, o[j].x), __fadd_rn(x4.y, o[j].y), __fadd_rn(x4.z, o[j].z), __fadd_rn(x4.w, o[j].w)};
+        if (FULL || m_blk + i * 4 + r4 < p.M) *reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc) = v;
+      }
     }
   };
 
@@ -373,6 +412,34 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
               }
           }
       }
+    } else if constexpr (RES && !PRE) {
+      char* fs = smem + fslot * STAGE;
+      const uint32_t h0 = lds_addr(fs + (wave * A_PW) * 1024);
+      const uint32_t h1 = lds_addr(fs + A_BYTES + (wave * B_PW) * 1024);
+      const uint32_t wbase = ((lr >> 4) ? h1 : h0) + (lr & 15) * 256;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m_blk = m0 + wm * MT * 32 + mt * 32;
+        int b = ((FULL || m_blk + lr < p.M) ? m_blk + lr : p.M - 1) / p.L;
+        if (b > p.B - 1) b = p.B - 1;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+          f32x4_t bb[4];
+          lds_read4x16(bb, lds_addr(auxf + nb0 + nt * 32 + 4 * lh));
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            f32x4_t v = {acc[nt][mt][4 * g + 0] + bb[g].x, acc[nt][mt][4 * g + 1] + bb[g].y,
+                         acc[nt][mt][4 * g + 2] + bb[g].z, acc[nt][mt][4 * g + 3] + bb[g].w};
+            if constexpr (EPI == EPI_GATE_RES) {
+              const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 8 * g + 4 * lh);
+              v = f32x4_t{__fmul_rn(v.x, g4.x), __fmul_rn(v.y, g4.y), __fmul_rn(v.z, g4.z), __fmul_rn(v.w, g4.w)};
+            }
+            lds_write16(wbase + (((nt * 8 + 2 * g + lh) ^ (lr & 7)) << 4), v);
+          }
+        }
+        res_block(m_blk, nb0, h0, h1, full_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
     } else {
       f32x4_t bb[NT][4];
 #pragma unroll
@@ -410,16 +477,17 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
               for (int q = 0; q < 4; ++q) v[q] = epi_gelu_erf(v[q]);
             }
             if constexpr (RES) {
-              if (mok) {
-                const float4 r = res[(mt * NT + nt) * 4 + g];
-                float4 o;
-                if constexpr (EPI == EPI_GATE_RES) {
-                  const float4 g4 = gg[nt * 4 + g];   // v already holds acc + bias: fma(acc + bias, gate, xin)
-                  o = make_float4(fmaf(v[0], g4.x, r.x), fmaf(v[1], g4.y, r.y), fmaf(v[2], g4.z, r.z), fmaf(v[3], g4.w, r.w));
-                } else {
-                  o = make_float4(r.x + v[0], r.y + v[1], r.z + v[2], r.w + v[3]);
+              if constexpr (EPI == EPI_GATE_RES) {   // v already holds acc + bias (epi_gate_mul / epi_gate_res)
+                const float4 g4 = gg[nt * 4 + g];
+                v[0] = __fmul_rn(v[0], g4.x); v[1] = __fmul_rn(v[1], g4.y);
+                v[2] = __fmul_rn(v[2], g4.z); v[3] = __fmul_rn(v[3], g4.w);
+              }
+              if constexpr (PRE) {
+                if (mok) {
+                  const float4 r = res[(mt * NT + nt) * 4 + g];
+                  const float4 o = make_float4(__fadd_rn(r.x, v[0]), __fadd_rn(r.y, v[1]), __fadd_rn(r.z, v[2]), __fadd_rn(r.w, v[3]));
+                  *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = o;
                 }
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = o;
               }
             } else {
               pk[nt][g] = pack4(v[0], v[1], v[2], v[3]);
@@ -432,7 +500,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   };
 
   auto load_residual = [&](int m0, int n0) {
-    if constexpr (RES) {
+    if constexpr (PRE) {
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         int m = m0 + wm * MT * 32 + mt * 32 + lr;
@@ -498,7 +566,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // so the two waves of a SIMD share the VALU for their epilogues instead of running them one after
   // the other.  Both orders put the stores between stage(e+D) and stage(e+1+D) in the wave's VM queue
   // (e = last step of the tile), so the wait counts below are the same for both groups.
-  constexpr bool EARLY1 = !RES && !F32OUT;
+  constexpr bool EARLY1 = !PRE && !F32OUT;
   for (int ti = 0; ti < n_my; ++ti) {
     STAMP(7);
     if (ti > 0 && !(EARLY1 && grp == 1)) {
@@ -526,7 +594,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       stage(ps);
     }
     STAMP(0);
-    if (RES && LAST) {   // residual tile into registers, consumed by the epilogue one step later
+    if (PRE && LAST) {   // residual tile into registers, consumed by the epilogue one step later
       int m0, n0;
       tile_origin(ti, m0, n0);
       load_residual(m0, n0);
@@ -549,7 +617,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         // younger than stage s+1 besides the stages: the epilogue stores issued at kt = 0 (while
         // kt <= D-2), or the residual prefetch issued just above
         const bool ex_st = prev_full && ti > 0 && kt <= D - 2;
-        const bool ex_ld = RES && exact && LAST;
+        const bool ex_ld = PRE && exact && LAST;
         wait_stage(ahead, ex_st || ex_ld);
       }
       STAMP_TAKE(st_a);
@@ -681,7 +749,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #endif
   GemmParams q = p;
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
-  const bool big = !res && !f32out && tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096;
+  const bool big = !f32out && tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096;
   ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
 #define LAUNCH_BOTH(E)                                                              \
@@ -702,8 +770,8 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
       break;
     LAUNCH_BOTH(EPI_BIAS_GELU)
     LAUNCH_RES(EPI_BIAS_GELU_ERF)   // erff needs too many registers beside the 256x256 accumulators
-    LAUNCH_RES(EPI_GATE_RES)
-    LAUNCH_RES(EPI_RES)
+    LAUNCH_BOTH(EPI_GATE_RES)
+    LAUNCH_BOTH(EPI_RES)
     LAUNCH_RES(EPI_BIAS_F32)
     LAUNCH_RES(EPI_ACC_F32)
     default: break;
