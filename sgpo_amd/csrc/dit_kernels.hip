@@ -174,8 +174,9 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
 // Non-causal multi-head attention for short fixed-length sequences (L <= 512), head_dim 64.
 // Replaces flash_attn_varlen_qkvpacked_func (dit.py:272-273) for equal-length sequences.
 //
-// One workgroup (4 waves) per (sequence, head).  K [Lp][64] (XOR-swizzled 16-B chunks) and
-// V^T [64][Lp+4] live in LDS for the whole sequence.  A wave owns 32-query tiles and walks the
+// One workgroup (4 waves) per (sequence, head).  K [Lp][64] and V [Lp][64] (both row-major with
+// XOR-swizzled 16-B chunks) live in LDS for the whole sequence; V is consumed column-wise through the
+// transposing LDS read ds_read_b64_tr_b16 (4 keys x 16 d per 16-lane group), so no V^T image is built.  A wave owns 32-query tiles and walks the
 // key tiles with an online softmax.  Products are "swapped" so every per-query quantity
 // (max, sum, rescale) is lane-local:
 //     S^T[key][query] = K Q^T          A = K rows (LDS),  B = Q (registers)
@@ -189,12 +190,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hid = n_heads * ATT_D;
   const int ld = 3 * hid;
-  const int b = blockIdx.x / n_heads, h = blockIdx.x % n_heads;
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  The heads of one sequence read
+  // neighbouring 128-B pieces of the same qkv rows, so they are given ids 8 apart: same XCD (one L2),
+  // dispatched back to back.  Sequences beyond the last multiple of 8 use the plain order.
+  int b, h;
+  {
+    const int per = 8 * n_heads, grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+    const int n_seq = gridDim.x / n_heads;
+    if ((grp + 1) * 8 <= n_seq) { b = grp * 8 + (r & 7); h = r >> 3; }
+    else { b = blockIdx.x / n_heads; h = blockIdx.x % n_heads; }
+  }
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
-  const int vt_stride = Lp + 4;  // bf16 elements; (Lp/2 + 2) dwords = 2*odd -> conflict-free b64 reads
-  char* k_lds = smem;                                            // Lp * 128 B
-  bf16_t* vt_lds = reinterpret_cast<bf16_t*>(smem + Lp * 128);   // 64 * vt_stride
+  char* k_lds = smem;              // Lp * 128 B, chunk c of row r at c ^ ((r >> 1) & 7)
+  char* v_lds = smem + Lp * 128;   // Lp * 128 B, chunk c of row r at c ^ ((r & 3) << 1)
   const bf16_t* base = qkv + (size_t)b * L * ld + h * ATT_D;
 
   // ---- stage K (swizzled rows) and V^T; rows >= L are zero
@@ -206,11 +215,14 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
       vv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * hid + c * 8);
     }
     *reinterpret_cast<uint4*>(k_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-    const bf16_t* ve = reinterpret_cast<const bf16_t*>(&vv);
-#pragma unroll
-    for (int i = 0; i < 8; ++i) vt_lds[(c * 8 + i) * vt_stride + row] = ve[i];
+    *reinterpret_cast<uint4*>(v_lds + row * 128 + ((c ^ ((row & 3) << 1)) << 4)) = vv;
   }
   __syncthreads();
+  // transposed-read addressing (per 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3 of a 4-key x
+  // 16-d block and lane i receives column i): this lane's d is lr, its keys are 4 lh + {0..3} (+8)
+  const int tq = (lane >> 2) & 3, tp = lane & 3, dblk = lr >> 4;
+  const int v_off0 = (lh * 4 + tq) * 128 + (((dblk * 2 + (tp >> 1)) ^ (tq << 1)) << 4) + (tp & 1) * 8;        // d in [0, 32)
+  const int v_off1 = (lh * 4 + tq) * 128 + (((4 + dblk * 2 + (tp >> 1)) ^ (tq << 1)) << 4) + (tp & 1) * 8;    // d in [32, 64)
 
   const int n_tiles = Lp / 32;
   for (int qt = wave; qt < n_tiles; qt += 4) {
@@ -265,19 +277,18 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         bf16x8 pf;
 #pragma unroll
         for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[st * 8 + j];
-        const int kbase = kt * 32 + st * 16 + lh * 4;
-        // A operand: V^T[d = lr (+32)][same keys]: two 8-byte reads (keys kbase..+3, kbase+8..+11)
-        bf16x8 v0, v1;
-        {
-          const bf16_t* r0 = vt_lds + lr * vt_stride + kbase;
-          const bf16_t* r1 = vt_lds + (lr + 32) * vt_stride + kbase;
-          bf16x4 a = *reinterpret_cast<const bf16x4*>(r0);
-          bf16x4 c = *reinterpret_cast<const bf16x4*>(r0 + 8);
-          bf16x4 d = *reinterpret_cast<const bf16x4*>(r1);
-          bf16x4 e = *reinterpret_cast<const bf16x4*>(r1 + 8);
-          v0 = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
-          v1 = __builtin_shufflevector(d, e, 0, 1, 2, 3, 4, 5, 6, 7);
-        }
+        // A operand: V^T[d = lr (+32)][keys kt*32 + st*16 + 4 lh + {0..3, 8..11}] by transposed reads of V
+        const char* vb = v_lds + (kt * 32 + st * 16) * 128;
+        typedef short s16x4_t __attribute__((ext_vector_type(4)));
+        typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
+        const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off0));
+        const s16x4_t c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off0 + 8 * 128));
+        const s16x4_t d = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off1));
+        const s16x4_t e = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off1 + 8 * 128));
+        typedef short s16x8_t __attribute__((ext_vector_type(8)));
+        const s16x8_t v0s = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+        const s16x8_t v1s = __builtin_shufflevector(d, e, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 v0 = __builtin_bit_cast(bf16x8, v0s), v1 = __builtin_bit_cast(bf16x8, v1s);
         o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o0, 0, 0, 0);
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o1, 0, 0, 0);
       }
@@ -305,7 +316,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
 int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, int head_dim, hipStream_t stream) {
   SGPO_REQUIRE(head_dim == ATT_D, "attention: head_dim %d unsupported (64 only)", head_dim);
   const int Lp = (L + 31) / 32 * 32;
-  const size_t lds = (size_t)Lp * 128 + (size_t)64 * (Lp + 4) * 2;
+  const size_t lds = (size_t)Lp * 256;   // K and V images
   SGPO_REQUIRE(lds <= 160 * 1024, "attention: sequence length %d exceeds the LDS-resident limit", L);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
