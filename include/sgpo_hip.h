@@ -132,6 +132,14 @@ int sgpo_mlp_forward(sgpo_mlp* m, const int64_t* x, const float* t, int B, int L
 size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B);
 int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
                             void* workspace, size_t workspace_bytes, void* stream);
+/* The same for absorbing-state diffusion (MDLM), computing only the ratios the guided rates can depend on.
+ * At a position whose token is not `mask_index` the subs-parameterised prior of MDLM.p_sample
+ * (models/mdlm.py:164-182: carry-over one-hot plus move_chance_s in the mask column) is exactly 0 for
+ * every target except the token itself and the mask, so cls_guidance.py:38-52 multiplies every other
+ * ratio by 0: those entries are written as 0 here instead of being evaluated (entries at masked positions,
+ * and the mask column everywhere, are bit-identical to sgpo_guidance_ratio_mlp).  Same workspace. */
+int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index,
+                                      float* log_ratio, void* workspace, size_t workspace_bytes, void* stream);
 
 /* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb
  * (dit.py:494-515: mean-pool over L + Linear(hidden, 1); w_cls = its weight, [hidden] fp32).

@@ -45,6 +45,7 @@ SIGNATURES = {
     'sgpo_mlp_forward': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     'sgpo_mlp_workspace_bytes': (_sz, [_vp, _i]),
     'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'sgpo_guidance_ratio_mlp_absorbing': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sgpo_nos_workspace_bytes': (_sz, [_vp, _i, _i]),
     'sgpo_nos_denoise': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _u64, _u64, _u64,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

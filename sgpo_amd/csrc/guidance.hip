@@ -137,9 +137,12 @@ struct MlpDev {
   int n_read, alphabet, time_cond;
 };
 
+// lists (absorbing-state compaction, mask_index >= 0): per sequence cnt[2] = {#masked, #unmasked read slots},
+// then the masked slots and the unmasked slots, each in increasing order (uint16 [2][n_read])
 __global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* __restrict__ x, const float* __restrict__ t,
                                                       float t_scalar, int L, float* __restrict__ hpre,
-                                                      float* __restrict__ fout) {
+                                                      float* __restrict__ fout, int mask_index, int* __restrict__ cnt,
+                                                      unsigned short* __restrict__ lists) {
   __shared__ float buf[2][MH];
   const int b = blockIdx.x, j = threadIdx.x;
   float pre = d.be1[j];
@@ -163,6 +166,22 @@ __global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* _
     pre += d.T1[((size_t)i * d.alphabet + tok) * MH + j];
   }
   if (hpre) hpre[(size_t)b * MH + j] = pre;
+  if (cnt) {
+    unsigned short* ml = lists + (size_t)b * 2 * d.n_read;
+    unsigned short* ul = ml + d.n_read;
+    int nm = 0, nu = 0;
+    for (int i0 = 0; i0 < d.n_read; i0 += 64) {
+      const int i = i0 + j;
+      const bool in = i < d.n_read;
+      const bool masked = in && (int)xr[d.read_pos[in ? i : 0]] == mask_index;
+      const unsigned long long bm = __ballot(masked), bu = __ballot(in && !masked);
+      const unsigned long long below = (1ull << j) - 1ull;
+      if (masked) ml[nm + __popcll(bm & below)] = (unsigned short)i;
+      if (in && !masked) ul[nu + __popcll(bu & below)] = (unsigned short)i;
+      nm += __popcll(bm); nu += __popcll(bu);
+    }
+    if (j == 0) { cnt[2 * b] = nm; cnt[2 * b + 1] = nu; }
+  }
   if (!fout) return;
   buf[0][j] = fmaxf(pre, 0.f);
   __syncthreads();
@@ -194,7 +213,7 @@ extern "C" int sgpo_mlp_forward(sgpo_mlp* m, const int64_t* x, const float* t, i
   SGPO_REQUIRE(m && x && out, "mlp_forward: null argument");
   SGPO_REQUIRE(B > 0 && L > 0, "mlp_forward: B=%d L=%d", B, L);
   hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mlp_dev(m), x, t, 0.f, L,
-                     (float*)nullptr, out);
+                     (float*)nullptr, out, -1, (int*)nullptr, (unsigned short*)nullptr);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
@@ -221,10 +240,18 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ wl /*LDS [t
   }
 }
 
+// Two tile kinds.  FULL: the S targets of one (b, slot).  PACKED (absorbing-state diffusion only): up to 31
+// unmasked slots of one sequence, each with the single target `mask_index`, plus the identity jump in
+// column 31 (f(x) with the same summation order, so the ratios equal the FULL tile's bit for bit).  At a
+// position whose token is not the mask, the prior rate is exactly 0 for every target except the mask and
+// the token itself (models/mdlm.py subs parameterisation + carry-over), so those are the only jumps that
+// can change the guided rates; the rest of the row stays at the zero the caller's memset left there.
 __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restrict__ w_perm, const float* __restrict__ bias_perm,
                                                        const float* __restrict__ T1, const int* __restrict__ read_pos,
                                                        const float* __restrict__ hpre, const int64_t* __restrict__ x,
-                                                       float b5, int n_tiles, int n_read, int alphabet, int S, int L,
+                                                       float b5, int B, int n_read, int alphabet, int S, int L,
+                                                       int mask_index, const int* __restrict__ cnt,
+                                                       const unsigned short* __restrict__ lists,
                                                        float* __restrict__ log_ratio) {
   __shared__ float wl[3 * MH * MH];
   __shared__ float bl[4 * MH];
@@ -234,93 +261,141 @@ __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restric
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int s = lane & 31, h = lane >> 5;
   const int n_waves = gridDim.x * 4;
-  for (int tile = blockIdx.x * 4 + wave; tile < n_tiles; tile += n_waves) {
-    // The 192 weight fragments are the same for every tile; hoisted out of this loop they would need
-    // 192 VGPRs and spill to scratch.  An opaque (always zero) offset keeps the LDS reads inside.
-    int wofs = 0;
-    asm volatile("" : "+s"(wofs));
-    const float* wt = wl + wofs;
-    const int b = tile / n_read, i = tile % n_read;
-    int xi = (int)x[(size_t)b * L + read_pos[i]];
-    xi = xi < 0 ? 0 : (xi >= alphabet ? alphabet - 1 : xi);
-    const int sc = s < S ? s : S - 1;
+  const bool compact = cnt != nullptr;
+  const int mask_tok = mask_index < 0 ? 0 : (mask_index >= alphabet ? alphabet - 1 : mask_index);
+  // compact: a wave walks whole sequences (their tile counts differ); otherwise tiles are dealt singly
+  const int n_units = compact ? B : B * n_read;
+  for (int unit = blockIdx.x * 4 + wave; unit < n_units; unit += n_waves) {
+    const int b = compact ? unit : unit / n_read;
+    int nm = 1, nu = 0;
+    if (compact) { nm = cnt[2 * b]; nu = cnt[2 * b + 1]; }
+    const int n_t = compact ? nm + (nu + 30) / 31 : 1;
+    const unsigned short* ml = compact ? lists + (size_t)b * 2 * n_read : nullptr;
     const float* hp = hpre + (size_t)b * MH;
-    const float* tn = T1 + ((size_t)i * alphabet + sc) * MH;
-    const float* to_ = T1 + ((size_t)i * alphabet + xi) * MH;
-    f32x16 a[2], o[2];
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int u = 32 * t + 8 * g + 4 * h;
-        const float4 p4 = *reinterpret_cast<const float4*>(hp + u);
-        const float4 n4 = *reinterpret_cast<const float4*>(tn + u);
-        const float4 o4 = *reinterpret_cast<const float4*>(to_ + u);
-        const bool same = (sc == xi);  // identity jump: exactly f(x)
-        a[t][g * 4 + 0] = fmaxf(same ? p4.x : (p4.x + n4.x - o4.x), 0.f);
-        a[t][g * 4 + 1] = fmaxf(same ? p4.y : (p4.y + n4.y - o4.y), 0.f);
-        a[t][g * 4 + 2] = fmaxf(same ? p4.z : (p4.z + n4.z - o4.z), 0.f);
-        a[t][g * 4 + 3] = fmaxf(same ? p4.w : (p4.w + n4.w - o4.w), 0.f);
+    for (int j = 0; j < n_t; ++j) {
+      // The 192 weight fragments are the same for every tile; hoisted out of this loop they would need
+      // 192 VGPRs and spill to scratch.  An opaque (always zero) offset keeps the LDS reads inside.
+      int wofs = 0;
+      asm volatile("" : "+s"(wofs));
+      const float* wt = wl + wofs;
+      const bool packed = compact && j >= nm;
+      // this lane's jump: slot i, target token sc; `ident`: no jump at all (f(x))
+      int i, sc;
+      bool live = true, ident = false;
+      if (!packed) {
+        i = compact ? (int)ml[j] : unit % n_read;
+        sc = s < S ? s : S - 1;
+        live = s < S;
+      } else {
+        const int u = (j - nm) * 31 + s;
+        ident = (s == 31);
+        live = !ident && u < nu;
+        i = live ? (int)ml[n_read + u] : (int)ml[n_read];   // any valid slot for idle lanes
+        sc = mask_tok;
       }
-    // mlp.2 + ReLU
-    mfma_layer(wt, a, o, lane);
+      int xi = (int)x[(size_t)b * L + read_pos[i]];
+      xi = xi < 0 ? 0 : (xi >= alphabet ? alphabet - 1 : xi);
+      const float* tn = T1 + ((size_t)i * alphabet + sc) * MH;
+      const float* to_ = T1 + ((size_t)i * alphabet + xi) * MH;
+      const bool same = ident || (sc == xi);  // identity jump: exactly f(x)
+      f32x16 a[2], o[2];
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) o[t][r] = fmaxf(o[t][r] + bl[0 * MH + (t * 16 + r) * 2 + h], 0.f);
-    // mlp.4 (no activation)
-    mfma_layer(wt + MH * MH, o, a, lane);
+        for (int g = 0; g < 4; ++g) {
+          const int u = 32 * t + 8 * g + 4 * h;
+          const float4 p4 = *reinterpret_cast<const float4*>(hp + u);
+          const float4 n4 = *reinterpret_cast<const float4*>(tn + u);
+          const float4 o4 = *reinterpret_cast<const float4*>(to_ + u);
+          a[t][g * 4 + 0] = fmaxf(same ? p4.x : (p4.x + n4.x - o4.x), 0.f);
+          a[t][g * 4 + 1] = fmaxf(same ? p4.y : (p4.y + n4.y - o4.y), 0.f);
+          a[t][g * 4 + 2] = fmaxf(same ? p4.z : (p4.z + n4.z - o4.z), 0.f);
+          a[t][g * 4 + 3] = fmaxf(same ? p4.w : (p4.w + n4.w - o4.w), 0.f);
+        }
+      // mlp.2 + ReLU
+      mfma_layer(wt, a, o, lane);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) a[t][r] = a[t][r] + bl[1 * MH + (t * 16 + r) * 2 + h];
-    // cls_head.0 + ReLU
-    mfma_layer(wt + 2 * MH * MH, a, o, lane);
-    float f = 0.f;
+        for (int r = 0; r < 16; ++r) o[t][r] = fmaxf(o[t][r] + bl[0 * MH + (t * 16 + r) * 2 + h], 0.f);
+      // mlp.4 (no activation)
+      mfma_layer(wt + MH * MH, o, a, lane);
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
+      for (int t = 0; t < 2; ++t)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const float v = fmaxf(o[t][r] + bl[2 * MH + (t * 16 + r) * 2 + h], 0.f);
-        f = fmaf(v, bl[3 * MH + (t * 16 + r) * 2 + h], f);
-      }
-    f += __shfl_xor(f, 32);
-    f += b5;
-    const float fbase = __shfl(f, xi);
-    if (h == 0 && s < S) log_ratio[((size_t)b * n_read + i) * S + s] = (s == xi) ? 0.f : f - fbase;
+        for (int r = 0; r < 16; ++r) a[t][r] = a[t][r] + bl[1 * MH + (t * 16 + r) * 2 + h];
+      // cls_head.0 + ReLU
+      mfma_layer(wt + 2 * MH * MH, a, o, lane);
+      float f = 0.f;
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float v = fmaxf(o[t][r] + bl[2 * MH + (t * 16 + r) * 2 + h], 0.f);
+          f = fmaf(v, bl[3 * MH + (t * 16 + r) * 2 + h], f);
+        }
+      f += __shfl_xor(f, 32);
+      f += b5;
+      const float fbase = __shfl(f, packed ? 31 : xi);   // FULL: xi is the same in every lane
+      if (h == 0 && live) log_ratio[((size_t)b * n_read + i) * S + sc] = (sc == xi) ? 0.f : f - fbase;
+    }
   }
 }
 
+static size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
+
+// hpre [B][64] f32 | cnt [B][2] i32 | lists [B][2][n_read] u16
 extern "C" size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B) {
   if (!m || B <= 0) return 0;
-  return ((size_t)B * MH * sizeof(float) + 255) & ~(size_t)255;
+  return al256((size_t)B * MH * sizeof(float)) + al256((size_t)B * 2 * sizeof(int)) +
+         al256((size_t)B * 2 * m->n_read * sizeof(unsigned short));
 }
 
-extern "C" int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
-                                       void* workspace, size_t workspace_bytes, void* stream) {
+static int guidance_ratio(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index, float* log_ratio,
+                          void* workspace, size_t workspace_bytes, void* stream) {
   SGPO_REQUIRE(m && x && log_ratio && workspace, "guidance_ratio_mlp: null argument");
   SGPO_REQUIRE(B > 0 && L > 0 && S > 0 && S <= 32 && S <= m->alphabet, "guidance_ratio_mlp: B=%d L=%d S=%d (S <= min(32, alphabet))", B, L, S);
+  SGPO_REQUIRE(mask_index < S, "guidance_ratio_mlp: mask_index %d outside the %d target states", mask_index, S);
+  SGPO_REQUIRE(m->n_read < 65536, "guidance_ratio_mlp: n_read %d", m->n_read);
   if (workspace_bytes < sgpo_mlp_workspace_bytes(m, B)) {
     sgpo_set_error("guidance_ratio_mlp: workspace %zu < required %zu bytes", workspace_bytes, sgpo_mlp_workspace_bytes(m, B));
     return SGPO_ERR_WORKSPACE;
   }
   hipStream_t st = (hipStream_t)stream;
-  float* hpre = (float*)workspace;
+  char* w = (char*)workspace;
+  float* hpre = (float*)w;
+  int* cnt = (int*)(w + al256((size_t)B * MH * sizeof(float)));
+  unsigned short* lists = (unsigned short*)((char*)cnt + al256((size_t)B * 2 * sizeof(int)));
+  const bool compact = mask_index >= 0;
+  if (compact) SGPO_CHECK_HIP(hipMemsetAsync(log_ratio, 0, (size_t)B * m->n_read * S * sizeof(float), st));
   {
     ProfScope prof_scope(PK_MLP_BASE, st, (double)B * m->n_read * MH * 4.0);
     hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, st, mlp_dev(m), x, (const float*)nullptr, t, L, hpre,
-                       (float*)nullptr);
+                       (float*)nullptr, mask_index, compact ? cnt : (int*)nullptr, compact ? lists : (unsigned short*)nullptr);
   }
-  const int n_tiles = B * m->n_read;
-  int blocks = (n_tiles + 3) / 4;
+  const int n_units = compact ? B : B * m->n_read;
+  int blocks = (n_units + 3) / 4;
   if (blocks > 256 * 3) blocks = 256 * 3;  // 3 resident blocks per CU (LDS 49 KiB each), grid-stride the rest
-  float b5;
-  // b5 lives in device memory; it is added to both f and fbase and cancels in the ratio.
-  b5 = 0.f;
-  // factored jump cost: three 64x64 layers + first-layer update + head per (b, i, s)
-  ProfScope prof_scope(PK_MLP_JUMP, st, (double)n_tiles * S * (3.0 * 2 * MH * MH + 5.0 * MH));
+  // b5 is added to both f and fbase and cancels in the ratio.
+  const float b5 = 0.f;
+  // factored jump cost: three 64x64 layers + first-layer update + head per (b, i, s).  In compact mode the
+  // work depends on the data; the figure reported is its lower bound (every position unmasked: one jump each)
+  const double per_jump = 3.0 * 2 * MH * MH + 5.0 * MH;
+  ProfScope prof_scope(PK_MLP_JUMP, st, compact ? (double)B * m->n_read * per_jump : (double)B * m->n_read * S * per_jump);
   hipLaunchKernelGGL(mlp_jump_kernel, dim3(blocks), dim3(256), 0, st, m->w_perm, m->bias_perm, m->T1, m->read_pos, hpre, x,
-                     b5, n_tiles, m->n_read, m->alphabet, S, L, log_ratio);
+                     b5, B, m->n_read, m->alphabet, S, L, mask_index, compact ? cnt : (const int*)nullptr,
+                     compact ? lists : (const unsigned short*)nullptr, log_ratio);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
+}
+
+extern "C" int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, float* log_ratio,
+                                       void* workspace, size_t workspace_bytes, void* stream) {
+  return guidance_ratio(m, x, t, B, L, S, -1, log_ratio, workspace, workspace_bytes, stream);
+}
+
+extern "C" int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index,
+                                                 float* log_ratio, void* workspace, size_t workspace_bytes, void* stream) {
+  SGPO_REQUIRE(mask_index >= 0, "guidance_ratio_mlp_absorbing: mask_index %d", mask_index);
+  return guidance_ratio(m, x, t, B, L, S, mask_index, log_ratio, workspace, workspace_bytes, stream);
 }

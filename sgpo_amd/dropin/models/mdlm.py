@@ -195,12 +195,16 @@ class MDLM(GenerativeModel):
                                 noise=self._next_noise())
 
     # ------------------------------------------------------------------ guidance
-    def _jump_log_ratios(self, predictor_model, x, t):
-        """(compact log-ratios (B,n_slots,S), slot_of_pos (L,) int32 or None)."""
+    def _jump_log_ratios(self, predictor_model, x, t, skip_zero_rate=False):
+        """(compact log-ratios (B,n_slots,S), slot_of_pos (L,) int32 or None).
+
+        skip_zero_rate: only for the fused absorbing-state step, whose prior is exactly 0 wherever the
+        skipped ratios would be used (include/sgpo_hip.h, sgpo_guidance_ratio_mlp_absorbing)."""
         vf = getattr(predictor_model, 'hip_value_function', None)
         if vf is not None:
             vf = vf()
-            lr = vf.jump_log_ratios(x, float(t), self.S)
+            mi = self.model.mask_index if (skip_zero_rate and self.diffusion == 'absorbing_state') else None
+            lr = vf.jump_log_ratios(x, float(t), self.S, mask_index=mi)
             return lr, _slot_map(vf.read_pos, x.shape[1], x.device)
         return _generic_jump_log_ratios(predictor_model, x, t, self.S), None
 
@@ -234,7 +238,7 @@ class MDLM(GenerativeModel):
         logits = self._denoise(x, sig_t)
         lr = slots = None
         if predictor_model is not None and guide_temp != 0:
-            lr, slots = self._jump_log_ratios(predictor_model, x, t)
+            lr, slots = self._jump_log_ratios(predictor_model, x, t, skip_zero_rate=True)
         xo, p = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_SOFT_CG,
                                      noise_src=self.noise_source, noise=self._next_noise(), log_ratio=lr,
                                      slot_of_pos=slots, guide_temp=guide_temp, want_probs=want_probs,

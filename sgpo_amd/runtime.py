@@ -180,8 +180,11 @@ class MlpValueFunction:
                 'sgpo_mlp_forward')
         return out
 
-    def jump_log_ratios(self, x, t, S, out=None):
-        """log_ratio (B, n_read, S) = f(x with x[read_pos[i]] <- s, t) - f(x, t)."""
+    def jump_log_ratios(self, x, t, S, out=None, mask_index=None):
+        """log_ratio (B, n_read, S) = f(x with x[read_pos[i]] <- s, t) - f(x, t).
+
+        mask_index (absorbing-state diffusion only): skip the jumps whose prior rate is exactly 0, i.e. at
+        unmasked positions evaluate only the jump to the mask and leave the other entries 0."""
         B, Lq = x.shape
         x = x.contiguous()
         if max(self.read_pos) >= Lq:
@@ -191,8 +194,13 @@ class MlpValueFunction:
         base = (ws.data_ptr() + 255) & ~255
         if out is None:
             out = torch.empty(B, self.n_read, S, dtype=torch.float32, device=self.device)
-        L.check(self.lib.sgpo_guidance_ratio_mlp(self.handle, L.ptr(x), float(t), B, Lq, S, L.ptr(out),
-                                                 C.c_void_p(base), need, L.stream_ptr()), 'sgpo_guidance_ratio_mlp')
+        if mask_index is None:
+            L.check(self.lib.sgpo_guidance_ratio_mlp(self.handle, L.ptr(x), float(t), B, Lq, S, L.ptr(out),
+                                                     C.c_void_p(base), need, L.stream_ptr()), 'sgpo_guidance_ratio_mlp')
+        else:
+            L.check(self.lib.sgpo_guidance_ratio_mlp_absorbing(self.handle, L.ptr(x), float(t), B, Lq, S, int(mask_index),
+                                                               L.ptr(out), C.c_void_p(base), need, L.stream_ptr()),
+                    'sgpo_guidance_ratio_mlp_absorbing')
         return out
 
 

@@ -205,6 +205,39 @@ def test_mlp_forward_and_jump_ratios(rt):
             assert float((lpj - lp.view(2, 1, 1))[:, others, :].abs().max()) < 1e-5
 
 
+def test_absorbing_jump_ratios_skip_only_zero_rate_entries(rt):
+    """sgpo_guidance_ratio_mlp_absorbing: bit-identical to the full kernel at masked positions and in the
+    mask column; 0 elsewhere; and the guided step (whose prior is 0 at the skipped entries) gives the
+    same probabilities and tokens bit for bit."""
+    from sgpo_amd import _lib as L
+    from sgpo_amd import weights as W
+    MASK, K = 28, 31
+    g = torch.Generator().manual_seed(5)
+    for Lq, read_pos, B in ((119, list(range(119)), 37), (40, [1, 5, 6, 17, 33, 39], 9), (70, list(range(70)), 64)):
+        msd = W.mlp_synthetic_state(seed=3, n_residues=len(read_pos))
+        vf = rt.MlpValueFunction(msd, read_pos)
+        x = torch.randint(0, 26, (B, Lq), generator=g)
+        frac = torch.rand(B, 1, generator=g)                 # from fully masked to fully unmasked rows
+        frac[0], frac[1] = 1.0, 0.0
+        x[torch.rand(B, Lq, generator=g) < frac] = MASK
+        xd = x.cuda()
+        full = vf.jump_log_ratios(xd, 5.0, K).clone()
+        comp = vf.jump_log_ratios(xd, 5.0, K, mask_index=MASK).clone()
+        masked = (x[:, read_pos] == MASK).cuda()
+        assert torch.equal(comp[masked], full[masked])
+        assert torch.equal(comp[..., MASK], full[..., MASK])
+        other = torch.ones(K, dtype=torch.bool); other[MASK] = False
+        assert float(comp[~masked][:, other.cuda()].abs().max()) == 0.0
+        if len(read_pos) == Lq:
+            logits = torch.randn(B, Lq, K, generator=g).cuda()
+            e = torch.empty(B, Lq, K).exponential_(1, generator=g).cuda()
+            a = rt.reverse_step_mdlm(logits, xd, 0.6, 0.3, MASK, L.STEP_SOFT_CG, noise=e, log_ratio=full, guide_temp=0.064,
+                                     want_probs=True)
+            b = rt.reverse_step_mdlm(logits, xd, 0.6, 0.3, MASK, L.STEP_SOFT_CG, noise=e, log_ratio=comp, guide_temp=0.064,
+                                     want_probs=True)
+            assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+
+
 def test_cg_step_against_golden(rt):
     """One guided step: q -> (q - 1_x) * ratio + 1_x -> clamp -> normalise (cls_guidance.py:38-51)."""
     from oracle import cls_guidance as ocg
