@@ -185,7 +185,7 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
 // qkv: [M][3*Hd] bf16 (q | k | v sections, heads contiguous inside a section), RoPE already applied.
 #define ATT_D 64
 
-__global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(256, 5) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                         int L, int Lp, int n_heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hid = n_heads * ATT_D;
@@ -252,19 +252,20 @@ __global__ __launch_bounds__(256) void attention_kernel(const bf16_t* __restrict
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
       }
       // s[r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*lh][query = lr]  (unscaled)
-      float tmax = -1e30f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        s[r] = (key < L) ? s[r] * scale_log2e : -1e30f;
-        tmax = fmaxf(tmax, s[r]);
+        if (key >= L) s[r] = -1e30f;
       }
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32));
+      float tmax = s[0];
+#pragma unroll
+      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
+      tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale_log2e;   // scale > 0: max commutes with it
       const float m_new = fmaxf(m_run, tmax);
-      const float alpha = exp2f(m_run - m_new);
+      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = exp2f(s[r] - m_new); psum += s[r]; }
+      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_new)); psum += s[r]; }
       psum += __shfl_xor(psum, 32);
       l_run = l_run * alpha + psum;
       m_run = m_new;
