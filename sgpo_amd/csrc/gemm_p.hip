@@ -306,7 +306,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       u32x4_t v = o[i];
       if (i & 1) v = u32x4_t{o[i].z, o[i].w, o[i].x, o[i].y};   // rows with bit 3 set hold swapped halves
       if (FULL || m_blk + i * 8 + r8 < p.M)
-        *reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc) = v;
+        __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc));   // streamed once: keep L2 for the operand panels
     }
   };
 
@@ -325,7 +325,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     for (int i = 0; i < 8; ++i) {
       size_t ro = (size_t)(i * 4) * p.ldc;
       if (!FULL && m_blk + i * 4 + r4 > p.M - 1) ro = 0;   // any valid row: the value is not stored
-      xr[i] = *reinterpret_cast<const f32x4_t*>(xp + ro);
+      xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xp + ro));
     }
     const uint32_t k0 = r4 * 256 + ((c16 ^ r4) << 4), k1 = r4 * 256 + ((c16 ^ (r4 + 4)) << 4);
 #pragma unroll
@@ -338,7 +338,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         const int i = hf * 4 + j;
         const f32x4_t x4 = xr[i];
         const f32x4_t v = {__fadd_rn(x4.x, o[j].x), __fadd_rn(x4.y, o[j].y), __fadd_rn(x4.z, o[j].z), __fadd_rn(x4.w, o[j].w)};
-        if (FULL || m_blk + i * 4 + r4 < p.M) *reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc) = v;
+        if (FULL || m_blk + i * 4 + r4 < p.M) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc));
       }
     }
   };
