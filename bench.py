@@ -206,6 +206,27 @@ def main():
             roof['denoiser_tflops'] = round(gf / (gt * 1e-3) / 1e12, 2)
             roof['gpu_busy_frac'] = round(tot * 1e-3 / dt, 4)
 
+    # row f-1 (the step right after the path): fitness-oracle ensemble on the sampled batch, timed
+    # outside the headline region (the reference evaluates it in dataset.update_data, not in inference())
+    fit = None
+    if rank == 0:
+        from sgpo_amd import runtime as rt
+        from sgpo_amd import weights as W
+        ens = rt.FitnessEnsemble(W.oracle_ensemble_synthetic_state(seed=2, n_members=10, n_res=119), device=device)
+        xs = out[0][:B].to(torch.int64).clamp(max=19)          # tokens outside the 20 letters raise in the reference
+        parent = torch.tensor([ALPHABET.index(c) for c in CREILOV], device=device)
+        ens.forward(xs, parent, 70, 0.99)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(5):
+            ens.forward(xs, parent, 70, 0.99)
+        e1.record()
+        torch.cuda.synchronize()
+        fms = e0.elapsed_time(e1) / 5
+        fit = dict(workload='fitness-oracle ensemble, 10 members x (2380 -> 400 -> 1), %d sequences' % B,
+                   ms=round(fms, 3), sequences_per_s=round(B / (fms * 1e-3), 1),
+                   table_gather_GBps=round(B * 10 * 119 * 400 * 4 / (fms * 1e-3) / 1e9, 1))
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline:
@@ -220,7 +241,7 @@ def main():
                        'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate',
                        'value_function': 'MLPModel hidden 64, fp32', 'global_batch': world * B,
                        'parallelism': f'dp{world} (independent shards + all-gather of tokens/scores)'},
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels,
+            'roofline': roof, 'cpu_baseline': cpu, 'fitness_ensemble': fit, 'kernels': kernels,
         }
         print(json.dumps(line))
     if world > 1:

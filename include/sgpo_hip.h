@@ -141,6 +141,24 @@ int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L
 int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index,
                                       float* log_ratio, void* workspace, size_t workspace_bytes, void* stream);
 
+/* ---- fitness-oracle ensemble: oracle/inference_oracle.py:19-72 ---------
+ * OracleModel (oracle/train_oracle.py:61-74) = Linear(20*n_res, hidden) -> ReLU -> Linear(hidden, 1) on the
+ * one-hot of the 20-letter alphabet 'ACDEFGHIKLMNPQRSTVWY' (train_oracle.py:39-48), n_members of them.
+ * blob (fp32, device), per member in order: fc1.weight [hidden][20*n_res], fc1.bias [hidden],
+ * fc2.weight [hidden], fc2.bias [1].
+ * forward: tokens [N][n_res] int64 (index into the 20-letter alphabet = the tokenizer id for these letters);
+ * parent_tokens [n_res] (NULL: impose_penalty=False); out[n] = mean over members of
+ * max(pred * (hd <= cutoff ? 1 : rate^(hd - cutoff)), 0) in fp64, hd = Hamming distance to the parent
+ * (inference_oracle.py:10-17,47-68).  *bad_token_flag (device int, may be NULL) is set when a token lies
+ * outside [0, 20) -- the reference raises ValueError there.  workspace: sgpo_fitness_workspace_bytes(N). */
+typedef struct sgpo_fitness sgpo_fitness;
+int sgpo_fitness_create(const float* blob, size_t n_floats, int n_members, int n_res, int hidden, sgpo_fitness** out);
+void sgpo_fitness_destroy(sgpo_fitness* m);
+size_t sgpo_fitness_workspace_bytes(const sgpo_fitness* m, int N);
+int sgpo_fitness_forward(sgpo_fitness* m, const int64_t* tokens, int N, const int64_t* parent_tokens, int cutoff,
+                         double rate, double* out, int* bad_token_flag, void* workspace, size_t workspace_bytes,
+                         void* stream);
+
 /* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb
  * (dit.py:494-515: mean-pool over L + Linear(hidden, 1); w_cls = its weight, [hidden] fp32).
  * One backbone pass, then num_nos_steps closed-form gradient + Adagrad updates of delta
@@ -222,7 +240,7 @@ int sgpo_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
  * preallocates events for n launches; read() synchronises and returns, per kernel kind,
  * total milliseconds, launch count and total algorithmic work (flops for MFMA kernels,
  * bytes for HBM-bound kernels).  SGPO_PROF_KINDS slots are required. */
-#define SGPO_PROF_KINDS 17
+#define SGPO_PROF_KINDS 18
 int sgpo_prof_enable(int on, int max_launches);
 int sgpo_prof_reset(void);
 int sgpo_prof_read(int n_kinds, double* total_ms, int64_t* launches, double* work);

@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('SGPO_HIP_LIB') or os.path.join(_HERE, 'libsgpo_hip.so
 
 NOISE_PHILOX, NOISE_EXPONENTIAL, NOISE_UNIFORM, NOISE_NONE = 0, 1, 2, 3
 STEP_SOFT, STEP_SOFT_CG, STEP_HARD = 0, 1, 2
-PROF_KINDS = 17
+PROF_KINDS = 18
 
 
 class SgpoError(RuntimeError):
@@ -46,6 +46,10 @@ SIGNATURES = {
     'sgpo_mlp_workspace_bytes': (_sz, [_vp, _i]),
     'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sgpo_guidance_ratio_mlp_absorbing': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'sgpo_fitness_create': (_i, [_vp, _sz, _i, _i, _i, C.POINTER(_vp)]),
+    'sgpo_fitness_destroy': (None, [_vp]),
+    'sgpo_fitness_workspace_bytes': (_sz, [_vp, _i]),
+    'sgpo_fitness_forward': (_i, [_vp, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _vp, _sz, _vp]),
     'sgpo_nos_workspace_bytes': (_sz, [_vp, _i, _i]),
     'sgpo_nos_denoise': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _u64, _u64, _u64,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

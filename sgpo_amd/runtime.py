@@ -204,6 +204,61 @@ class MlpValueFunction:
         return out
 
 
+class FitnessEnsemble:
+    """The fitness-oracle ensemble of oracle/inference_oracle.py on the GPU.
+
+    states: list of OracleModel state dicts (fc1.weight, fc1.bias, fc2.weight, fc2.bias)."""
+
+    def __init__(self, states, device=None):
+        self.device = init(device)
+        self.lib = L.load()
+        self.n_members = len(states)
+        self.hidden, in_dim = states[0]['fc1.weight'].shape
+        assert in_dim % 20 == 0
+        self.n_res = in_dim // 20
+        parts = []
+        for sd in states:
+            assert tuple(sd['fc1.weight'].shape) == (self.hidden, in_dim)
+            parts += [sd['fc1.weight'].reshape(-1), sd['fc1.bias'].reshape(-1), sd['fc2.weight'].reshape(-1),
+                      sd['fc2.bias'].reshape(-1)]
+        blob = torch.cat([q.to(torch.float32).cpu() for q in parts]).to(self.device).contiguous()
+        h = C.c_void_p()
+        L.check(self.lib.sgpo_fitness_create(L.ptr(blob), blob.numel(), self.n_members, self.n_res, self.hidden,
+                                             C.byref(h)), 'sgpo_fitness_create')
+        self.handle = h
+        self.ws = Workspace(self.device)
+        self._bad = torch.zeros(1, dtype=torch.int32, device=self.device)
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.sgpo_fitness_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def forward(self, tokens, parent_tokens=None, cutoff=0, rate=1.0):
+        """tokens (N, n_res) int64 indices into 'ACDEFGHIKLMNPQRSTVWY'; parent_tokens (n_res,) or None
+        (impose_penalty=False).  Returns float64 (N,).  Raises ValueError for a token outside the
+        alphabet, like `alphabet.index` in the reference (oracle/train_oracle.py:45)."""
+        N, n_res = tokens.shape
+        if n_res != self.n_res:
+            raise L.SgpoError(f'fitness ensemble trained on {self.n_res} residues, got {n_res}')
+        tokens = tokens.to(self.device, torch.int64).contiguous()
+        par = None if parent_tokens is None else parent_tokens.to(self.device, torch.int64).contiguous()
+        out = torch.empty(N, dtype=torch.float64, device=self.device)
+        need = self.lib.sgpo_fitness_workspace_bytes(self.handle, N)
+        ws = self.ws.get(need)
+        base = (ws.data_ptr() + 255) & ~255
+        L.check(self.lib.sgpo_fitness_forward(self.handle, L.ptr(tokens), N, L.ptr(par), int(cutoff), float(rate),
+                                              L.ptr(out), L.ptr(self._bad), C.c_void_p(base), need, L.stream_ptr()),
+                'sgpo_fitness_forward')
+        if int(self._bad.item()) != 0:
+            self._bad.zero_()
+            raise ValueError('substring not found')     # str.index's message in the reference
+        return out
+
+
 class NoiseSource:
     """Counter-based noise bookkeeping: one (seed, call offset) pair per sampling kernel call.
 

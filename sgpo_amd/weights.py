@@ -130,3 +130,19 @@ def load_lightning_state(path, prefix):
     if not out:
         raise KeyError(f'no keys with prefix {prefix!r} in {path}')
     return out
+
+
+def oracle_ensemble_synthetic_state(seed=0, n_members=10, n_res=119, hidden=400):
+    """Seeded fp32 state dicts of an OracleModel ensemble (oracle/train_oracle.py:61-74): fc1
+    (hidden x 20*n_res), fc2 (1 x hidden).  The output bias is shifted per member so that some
+    predictions are negative (exercises the max(., 0) of oracle/inference_oracle.py:62)."""
+    g = torch.Generator().manual_seed(seed)
+    out = []
+    for m in range(n_members):
+        sd = {}
+        sd.update(_lin(g, hidden, 20 * n_res, prefix='fc1.'))
+        sd.update(_lin(g, 1, hidden, prefix='fc2.'))
+        sd['fc1.weight'] = sd['fc1.weight'] * 3.0
+        sd['fc2.bias'] = sd['fc2.bias'] + 0.05 * (m % 3 - 1)
+        out.append(sd)
+    return out

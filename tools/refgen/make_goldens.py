@@ -370,7 +370,103 @@ def gen_nos():
     save('nos_small', **out)
 
 
-GENS = dict(dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
+def gen_oracle_ens():
+    """f-1: the reference's own inference_oracle (oracle/inference_oracle.py) on seeded synthetic
+    ensembles written to a temporary model_path, plus a generation-time check of the CPU restatement
+    against the reference with the checkpoints it ships (their weights are not committed)."""
+    import tempfile
+    import types
+    bio = standins._mod('Bio')
+    seqio = standins._mod('Bio.SeqIO')
+
+    def _parse(path, fmt):
+        recs, cur = [], None
+        for line in open(path):
+            line = line.strip()
+            if line.startswith('>'):
+                cur = types.SimpleNamespace(id=line[1:], seq='')
+                recs.append(cur)
+            elif cur is not None:
+                cur.seq += line
+        return recs
+    seqio.parse = _parse
+    seqio.read = lambda path, fmt: _parse(path, fmt)[0]
+    bio.SeqIO = seqio
+    standins._mod('wandb')
+    cwd = os.getcwd()
+    os.chdir(REF)                       # the reference opens data/<protein>/parent.fasta relative to cwd
+    try:
+        # the reference's `oracle` package (no __init__.py) shares its name with this repo's test
+        # oracle/ directory: bind the name to the reference directory for the duration of this generator
+        saved = {k: v for k, v in sys.modules.items() if k == 'oracle' or k.startswith('oracle.')}
+        for k in saved:
+            del sys.modules[k]
+        pkg = types.ModuleType('oracle')
+        pkg.__path__ = [os.path.join(REF, 'oracle')]
+        sys.modules['oracle'] = pkg
+        from oracle.inference_oracle import inference_oracle
+        import importlib.util
+        spec = importlib.util.spec_from_file_location('oracle_ens_port', os.path.join(ROOT, 'oracle', 'oracle_ensemble.py'))
+        port = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(port)
+        g = torch.Generator().manual_seed(77)
+        aa = port.AA20
+        out = {}
+        for protein, n_members, seed in (('CreiLOV', 10, 11), ('TrpB', 20, 12)):
+            parent = str(_parse(f'data/{protein}/parent.fasta', 'fasta')[0].seq)
+            if protein == 'CreiLOV':
+                n_res, base = len(parent), parent
+            else:
+                n_res, base = len(TRPB_RES), ''.join(parent[r - 1] for r in TRPB_RES)
+            # mutants of the parent (combo) at 0 .. n_res mutated positions, so the penalty branch is taken
+            seqs = []
+            for n_mut in [0, 1, 5, 30, 69, 70, 71, 72, 90, 110, 119][:11 if protein == 'CreiLOV' else 4] + [3, 8, 15][: 0 if protein == 'CreiLOV' else 3]:
+                n_mut = min(n_mut, n_res)
+                s = list(base)
+                for pos in torch.randperm(n_res, generator=g)[:n_mut].tolist():
+                    s[pos] = aa[(aa.index(s[pos]) + 1 + int(torch.randint(19, (1,), generator=g))) % 20]
+                seqs.append(''.join(s))
+            for _ in range(5):
+                seqs.append(''.join(aa[i] for i in torch.randint(20, (n_res,), generator=g).tolist()))
+            states = W.oracle_ensemble_synthetic_state(seed=seed, n_members=n_members, n_res=n_res)
+            with tempfile.TemporaryDirectory() as d:
+                for m, sd in enumerate(states):
+                    torch.save(sd, os.path.join(d, f'model{m}.pth'))
+                _, y = inference_oracle(seqs, protein=protein, model_path=d)
+                _, y_np = inference_oracle(seqs, protein=protein, model_path=d, impose_penalty=False)
+            mine = port.ensemble_fitness(states, seqs, parent, protein)
+            assert torch.allclose(mine, y, rtol=1e-6, atol=1e-7), (mine - y).abs().max()   # fp32 BLAS summation order
+            print('  max |restatement - reference| synthetic', float((mine - y).abs().max()))
+            # the shipped checkpoints: restatement vs reference, checked here only
+            real = [torch.load(f'oracle/checkpoints/{protein}/{f}', weights_only=True, map_location='cpu')
+                    for f in sorted(os.listdir(f'oracle/checkpoints/{protein}'))]
+            # the shipped tensors were saved from CUDA; the reference's torch.load has no map_location, so
+            # give this CPU-only process a default one (safe loader: weights_only stays at torch's default True)
+            _orig_load = torch.load
+            torch.load = lambda f, **kw: _orig_load(f, **{'map_location': 'cpu', 'weights_only': True, **kw})
+            try:
+                _, y_real = inference_oracle(seqs, protein=protein, model_path=f'oracle/checkpoints/{protein}')
+            finally:
+                torch.load = _orig_load
+            mine_real = port.ensemble_fitness(real, seqs, parent, protein)
+            assert torch.allclose(mine_real, y_real, rtol=1e-6, atol=1e-7), (mine_real - y_real).abs().max()
+            print(protein, 'reference == restatement on synthetic and shipped ensembles; y range', float(y.min()), float(y.max()),
+                  'real', float(y_real.min()), float(y_real.max()))
+            out[f'{protein}_seqs'] = np.array(seqs)
+            out[f'{protein}_parent'] = np.array(parent)
+            out[f'{protein}_y'] = y.numpy()
+            out[f'{protein}_y_nopenalty'] = y_np.numpy()
+            out[f'{protein}_seed'] = seed
+            out[f'{protein}_members'] = n_members
+        save('oracle_ens', **out)
+    finally:
+        os.chdir(cwd)
+        for k in [k for k in sys.modules if k == 'oracle' or k.startswith('oracle.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+GENS = dict(oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
