@@ -11,17 +11,6 @@
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-__device__ __forceinline__ float gelu_tanh_f(float x) {
-  // 0.5 x (1 + tanh(sqrt(2/pi) (x + 0.044715 x^3)))
-  float u = 0.7978845608028654f * (x + 0.044715f * x * x * x);
-  float e = __expf(2.0f * u);
-  float t = 1.0f - 2.0f / (e + 1.0f);
-  return 0.5f * x * (1.0f + t);
-}
-__device__ __forceinline__ float gelu_erf_f(float x) {
-  return 0.5f * x * (1.0f + erff(x * 0.7071067811865476f));
-}
-
 template <int EPI>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile + B tile)
