@@ -45,26 +45,36 @@ struct GemmParams {
 // Epilogue arithmetic shared by both GEMM kernels (gemm.hip, gemm_p.hip).  Every fused multiply-add is
 // explicit so the two kernels round identically: a batch sharded into pieces small enough for the
 // 128x128 kernel must reproduce the tokens of the unsharded batch bit for bit.
+// __fmul_rn / __fadd_rn are plain * and + in the ROCm headers and contract like any other expression,
+// so the uncontracted forms are spelled with the pragma.
+__device__ __forceinline__ float rn_mul(float a, float b) {
+#pragma clang fp contract(off)
+  return a * b;
+}
+__device__ __forceinline__ float rn_add(float a, float b) {
+#pragma clang fp contract(off)
+  return a + b;
+}
 __device__ __forceinline__ float epi_gelu_tanh(float x) {
   // 0.5 x (1 + tanh(u)) = x * sigmoid(2u),  2u = 2 sqrt(2/pi) (x + 0.044715 x^3) = x (c0 + c1 x^2);
   // sigmoid(2u) = 1 / (1 + exp2(x (k0 + k1 x^2))) with k = -c log2(e): 4 VALU + v_exp_f32 + v_rcp_f32
-  const float t = fmaf(-0.10294324f, __fmul_rn(x, x), -2.30220819f);
-  const float e = __builtin_amdgcn_exp2f(__fmul_rn(x, t));
-  return __fmul_rn(x, __builtin_amdgcn_rcpf(1.0f + e));
+  const float t = fmaf(-0.10294324f, rn_mul(x, x), -2.30220819f);
+  const float e = __builtin_amdgcn_exp2f(rn_mul(x, t));
+  return rn_mul(x, __builtin_amdgcn_rcpf(1.0f + e));
 }
 __device__ __forceinline__ float epi_gelu_erf(float x) {
-  return __fmul_rn(__fmul_rn(0.5f, x), 1.0f + erff(__fmul_rn(x, 0.7071067811865476f)));
+  return rn_mul(rn_mul(0.5f, x), 1.0f + erff(rn_mul(x, 0.7071067811865476f)));
 }
 __device__ __forceinline__ void epi_rope(float a, float b, float cs, float sn, float& o0, float& o1) {
-  o0 = fmaf(a, cs, -__fmul_rn(b, sn));   // x1 cos - x2 sin
-  o1 = fmaf(a, sn, __fmul_rn(b, cs));    // x1 sin + x2 cos
+  o0 = fmaf(a, cs, -rn_mul(b, sn));   // x1 cos - x2 sin
+  o1 = fmaf(a, sn, rn_mul(b, cs));    // x1 sin + x2 cos
 }
 // x + gate * (acc + bias), the product rounded before the add (two roundings, never contracted to an
 // fma): the 256x256 kernel forms the product in the accumulator layout and adds x after a transpose
 // through LDS, and both kernels must give the same bits.  (The reference rounds the product to bf16.)
-__device__ __forceinline__ float epi_gate_mul(float acc, float bias, float gate) { return __fmul_rn(acc + bias, gate); }
+__device__ __forceinline__ float epi_gate_mul(float acc, float bias, float gate) { return rn_mul(acc + bias, gate); }
 __device__ __forceinline__ float epi_gate_res(float acc, float bias, float gate, float xin) {
-  return __fadd_rn(xin, epi_gate_mul(acc, bias, gate));
+  return rn_add(xin, epi_gate_mul(acc, bias, gate));
 }
 
 struct GemmSeg {

@@ -337,7 +337,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       for (int j = 0; j < 4; ++j) {
         const int i = hf * 4 + j;
         const f32x4_t x4 = xr[i];
-        const f32x4_t v = {__fadd_rn(x4.x, o[j].x), __fadd_rn(x4.y, o[j].y), __fadd_rn(x4.z, o[j].z), __fadd_rn(x4.w, o[j].w)};
+        const f32x4_t v = {rn_add(x4.x, o[j].x), rn_add(x4.y, o[j].y), rn_add(x4.z, o[j].z), rn_add(x4.w, o[j].w)};
         if (FULL || m_blk + i * 4 + r4 < p.M) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc));
       }
     }
@@ -432,7 +432,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
                          acc[nt][mt][4 * g + 2] + bb[g].z, acc[nt][mt][4 * g + 3] + bb[g].w};
             if constexpr (EPI == EPI_GATE_RES) {
               const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 8 * g + 4 * lh);
-              v = f32x4_t{__fmul_rn(v.x, g4.x), __fmul_rn(v.y, g4.y), __fmul_rn(v.z, g4.z), __fmul_rn(v.w, g4.w)};
+              v = f32x4_t{rn_mul(v.x, g4.x), rn_mul(v.y, g4.y), rn_mul(v.z, g4.z), rn_mul(v.w, g4.w)};
             }
             lds_write16(wbase + (((nt * 8 + 2 * g + lh) ^ (lr & 7)) << 4), v);
           }
@@ -479,13 +479,13 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
             if constexpr (RES) {
               if constexpr (EPI == EPI_GATE_RES) {   // v already holds acc + bias (epi_gate_mul / epi_gate_res)
                 const float4 g4 = gg[nt * 4 + g];
-                v[0] = __fmul_rn(v[0], g4.x); v[1] = __fmul_rn(v[1], g4.y);
-                v[2] = __fmul_rn(v[2], g4.z); v[3] = __fmul_rn(v[3], g4.w);
+                v[0] = rn_mul(v[0], g4.x); v[1] = rn_mul(v[1], g4.y);
+                v[2] = rn_mul(v[2], g4.z); v[3] = rn_mul(v[3], g4.w);
               }
               if constexpr (PRE) {
                 if (mok) {
                   const float4 r = res[(mt * NT + nt) * 4 + g];
-                  const float4 o = make_float4(__fadd_rn(r.x, v[0]), __fadd_rn(r.y, v[1]), __fadd_rn(r.z, v[2]), __fadd_rn(r.w, v[3]));
+                  const float4 o = make_float4(rn_add(r.x, v[0]), rn_add(r.y, v[1]), rn_add(r.z, v[2]), rn_add(r.w, v[3]));
                   *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = o;
                 }
               }

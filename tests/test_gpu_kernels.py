@@ -81,7 +81,8 @@ def test_dit_forward(rt, name):
     assert err2 < 1e-2, f'x_emb path: {err2:.3e}'
 
 
-def test_dit_forward_large_batch_uses_persistent_gemm(rt):
+@pytest.mark.parametrize('B', [12, 36])     # M = 1428: 256x128 tiles only; M = 4284: 256x256 tiles with a ragged last tile
+def test_dit_forward_large_batch_uses_persistent_gemm(rt, B):
     """M = B*L >= 1024 routes every GEMM (all epilogues: RoPE, GELU, gate+residual, vocab head) through
     the persistent kernel; rows are independent, so the result must match the oracle like the small case."""
     from oracle import dit as odit
@@ -89,7 +90,7 @@ def test_dit_forward_large_batch_uses_persistent_gemm(rt):
     sd = W.dit_synthetic_state(seed=21)
     net = rt.DitDenoiser(sd)
     g = torch.Generator().manual_seed(9)
-    B, Lq = 12, 119                       # M = 1428: ragged last 256-row tile
+    Lq = 119
     x = torch.randint(0, 31, (B, Lq), generator=g)
     sigma = torch.rand(B, generator=g) * 3
     logits, hidden = net.forward(x.cuda(), sigma.cuda(), return_hidden=True)
@@ -103,6 +104,8 @@ def test_dit_forward_large_batch_uses_persistent_gemm(rt):
     #    bit for bit (shared epilogue arithmetic): sharding a batch never changes its samples
     small = net.forward(x[:2].cuda(), sigma[:2].cuda())
     assert torch.equal(small, logits[:2])
+    tail = net.forward(x[-2:].cuda(), sigma[-2:].cuda())          # rows of the ragged last tile
+    assert torch.equal(tail, logits[-2:])
 
 
 def test_dit_sigma_broadcast(rt):
