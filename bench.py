@@ -258,6 +258,35 @@ def main():
         fit = dict(workload='fitness-oracle ensemble, 10 members x (2380 -> 400 -> 1), %d sequences' % B,
                    ms=round(fms, 3), sequences_per_s=round(B / (fms * 1e-3), 1),
                    table_gather_GBps=round(B * 10 * 119 * 400 * 4 / (fms * 1e-3) / 1e9, 1))
+    # row f-2 (between the sampler and the fitness oracle): token-level project_sequences + update_data's
+    # de-duplication against a store that already holds the earlier batches; outside the headline region too
+    acq = None
+    if rank == 0:
+        from sgpo_amd import runtime as rt
+        xs = out[0][:B].to(torch.int64).contiguous()
+        Lx = xs.shape[1]
+        parent = torch.tensor([ALPHABET.index(c) for c in CREILOV], device=device)
+        gen = torch.Generator(device=device).manual_seed(3)
+        u = torch.rand(B, 11, device=device, generator=gen)
+        keys = torch.rand(B, Lx, device=device, generator=gen)
+        store = rt.AcquisitionSet(Lx, capacity=16 * B, max_batch=B, device=device)
+        reps = 8
+        batches = [torch.where(torch.rand(B, Lx, device=device, generator=gen) < 0.02,
+                               torch.randint(0, 20, (B, Lx), device=device, generator=gen), xs) for _ in range(reps + 1)]
+        rt.project_tokens(batches[0].clone(), parent, 20, 11, u, 10, keys)
+        store.update(batches[0], B, 1, 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        kept_total = 0
+        for r in range(reps):
+            y = rt.project_tokens(batches[r + 1], parent, 20, 11, u, 10, keys)
+            kept, _ = store.update(y, B, 1, r + 1)
+            kept_total += int(kept.numel())
+        torch.cuda.synchronize()
+        ams = (time.perf_counter() - t1) * 1e3 / reps
+        acq = dict(workload='project_tokens (n_max_mutations 10) + acquisition-set update (BO scope), %d x %d tokens' % (B, Lx),
+                   ms=round(ams, 3), sequences_per_s=round(B / (ams * 1e-3), 1), appended_per_call=kept_total / reps,
+                   note='wall clock incl. the two host synchronisations of sgpo_acq_update')
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline:
@@ -272,7 +301,7 @@ def main():
                        'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate',
                        'value_function': 'MLPModel hidden 64, fp32', 'global_batch': world * B,
                        'parallelism': f'dp{world} (independent shards + all-gather of tokens/scores)'},
-            'roofline': roof, 'cpu_baseline': cpu, 'fitness_ensemble': fit, 'kernels': kernels,
+            'roofline': roof, 'cpu_baseline': cpu, 'fitness_ensemble': fit, 'acquisition': acq, 'kernels': kernels,
         }
         print(json.dumps(line))
     if world > 1:

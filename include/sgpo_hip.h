@@ -159,6 +159,43 @@ int sgpo_fitness_forward(sgpo_fitness* m, const int64_t* tokens, int N, const in
                          double rate, double* out, int* bad_token_flag, void* workspace, size_t workspace_bytes,
                          void* stream);
 
+/* ---- batch hand-over between sampler and fitness oracle on token tensors ----
+ * Token-level Algo.project_sequences (sampling/base.py:40-63).  tokens [N][L] int64, repaired in place.
+ *  1. a token >= n_std (a special character, base.py:45-47) becomes floor(u * n_std) with
+ *     u = u_special[n][token - n_std]: one draw per distinct special token of a sequence, since
+ *     str.replace there replaces every occurrence at once.  u_special [N][n_special] fp32 in [0,1), or NULL
+ *     (then a special token sets bit 1 of *bad_flag and is left alone).
+ *  2. n_max_mutations >= 0 (the caller applies base.py:50's `n_residues > 4 and n_max_mutations is not None`):
+ *     of the positions that differ from full_seq [L], the n_max_mutations with the smallest keys[n][j]
+ *     (ties: smaller j) stay, the others are reverted to full_seq -- np.random.choice(mutated, k,
+ *     replace=False) of base.py:53-61 with the randomness handed in as iid keys [N][L] fp32.
+ * A token outside [0, n_std + n_special) sets bit 0 of *bad_flag (device int, may be NULL).  L <= 1024. */
+int sgpo_project_tokens(int64_t* tokens, const int64_t* full_seq, int N, int L, int n_std, int n_special,
+                        const float* u_special, int n_max_mutations, const float* keys, int* bad_flag, void* stream);
+/* The sequence store of ProteinPredictorDataset (dataset/protein.py:41-44,153-183) as a hash set in HBM.
+ * capacity: rows the store can hold; max_batch: largest N of one update; capacity + max_batch < 2^24. */
+typedef struct sgpo_acq sgpo_acq;
+int sgpo_acq_create(int L, size_t capacity, int max_batch, sgpo_acq** out);
+void sgpo_acq_destroy(sgpo_acq* a);
+long long sgpo_acq_count(const sgpo_acq* a);
+/* update_data's filter (dataset/protein.py:164-183) on tokens [N][L] int64 (values < 256).
+ * scope 0: keep every row (the reference's path when the store is empty, at the first call of a round without
+ *          BO, or with unique_only=False); 1: unique rows not yet in the store (BO=True, protein.py:168-170);
+ *          2: unique rows not appended during `round` (protein.py:171-173).
+ * Rows are kept in batch order (the reference's list(set(...)) order depends on the interpreter's string hash
+ * seed), the first n_needed of them (protein.py:178-179) are appended to the store with their round.
+ * kept_idx [N] int64 (device): batch rows appended, in order; *n_kept (host): how many; *n_admissible (host,
+ * may be NULL): how many passed the filter before truncation.  Synchronises the stream. */
+int sgpo_acq_update(sgpo_acq* a, const int64_t* tokens, int N, int n_needed, int scope, int round,
+                    int64_t* kept_idx, int* n_kept, int* n_admissible, void* stream);
+/* rows [first, first+count) of the store: out_tokens [count][L] int64 and/or out_rounds [count] int32 (device). */
+int sgpo_acq_read(const sgpo_acq* a, long long first, long long count, int64_t* out_tokens, int* out_rounds,
+                  void* stream);
+/* update_data's landscape branch (dataset/protein.py:188-197): table [n_std^n_res] fp32 indexed by the tokens at
+ * residues [n_res] (device int32), most significant first; combos the data frame lacks hold 0 (protein.py:193). */
+int sgpo_landscape_lookup(const float* table, size_t table_len, const int64_t* tokens, int N, int L,
+                          const int* residues, int n_res, int n_std, float* out, int* bad_flag, void* stream);
+
 /* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb
  * (dit.py:494-515: mean-pool over L + Linear(hidden, 1); w_cls = its weight, [hidden] fp32).
  * One backbone pass, then num_nos_steps closed-form gradient + Adagrad updates of delta

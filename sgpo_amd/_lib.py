@@ -50,6 +50,13 @@ SIGNATURES = {
     'sgpo_fitness_destroy': (None, [_vp]),
     'sgpo_fitness_workspace_bytes': (_sz, [_vp, _i]),
     'sgpo_fitness_forward': (_i, [_vp, _vp, _i, _vp, _i, C.c_double, _vp, _vp, _vp, _sz, _vp]),
+    'sgpo_project_tokens': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _i, _vp, _vp, _vp]),
+    'sgpo_acq_create': (_i, [_i, _sz, _i, C.POINTER(_vp)]),
+    'sgpo_acq_destroy': (None, [_vp]),
+    'sgpo_acq_count': (C.c_longlong, [_vp]),
+    'sgpo_acq_update': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
+    'sgpo_acq_read': (_i, [_vp, C.c_longlong, C.c_longlong, _vp, _vp, _vp]),
+    'sgpo_landscape_lookup': (_i, [_vp, _sz, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
     'sgpo_nos_workspace_bytes': (_sz, [_vp, _i, _i]),
     'sgpo_nos_denoise': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _u64, _u64, _u64,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

@@ -105,3 +105,18 @@ def inference_oracle(split, protein, model_path, impose_penalty=True, full_seq=N
     n_batches = (len(seqs) + 127) // 128               # len(test_loader), BATCH_SIZE = 128
     test_loss = torch.nn.functional.mse_loss(y, torch.zeros(len(seqs))) / n_batches   # "meaningless" for list splits
     return test_loss, y
+
+
+def inference_oracle_tokens(tokens, protein, model_path, impose_penalty=True, full_seq=None, device=None):
+    """The same ensemble on a token tensor (N, n_res) int64 (ids of the 20 letters = tokenizer ids): the
+    acquisition step's fast path (dataset/protein.py:185,202 without the strings).  Returns float64 (N,) on
+    the CPU like `inference_oracle`'s second value."""
+    ens = _ensemble(model_path, device)
+    if impose_penalty:
+        if full_seq is None:
+            full_seq = _read_fasta_first(f'data/{protein}/parent.fasta')
+        cutoff, rate = PENALTY[protein]
+        n = tokens.shape[1]
+        par_t = torch.tensor([AA20.index(c) if c in AA20 else -1 for c in str(full_seq)[:n]], dtype=torch.int64)
+        return ens.forward(tokens, par_t, cutoff, rate).cpu()
+    return ens.forward(tokens, None).cpu()

@@ -61,6 +61,18 @@ class Algo(ABC):
                 new_sequences[i] = ''.join(seq)
         return new_sequences
 
+    def project_tokens(self, x, generator=None):
+        """`project_sequences` on the token tensor (N, L) itself (HIP kernel):
+        no detokenise / re-tokenise round trip.  Same distribution as the string version; the draws come from
+        `generator` (torch) instead of numpy's global state.  Returns a repaired copy."""
+        from sgpo_amd import runtime as rt
+        x = x.to(torch.int64).contiguous().clone()
+        n_special = len(self.special_tokens)
+        u = torch.rand(x.shape[0], n_special, device=x.device, generator=generator)
+        cut = self.n_max_mutations if (self.n_residues > 4 and self.n_max_mutations is not None) else None
+        keys = torch.rand(x.shape, device=x.device, generator=generator) if cut is not None else None
+        return rt.project_tokens(x, self.full_seq.to(torch.int64), len(self.alphabet), n_special, u, cut, keys)
+
     def _untokenize_batch(self, x):
         xs = x.detach().cpu()
         return [self.net.tokenizer.untokenize(s) for s in xs]

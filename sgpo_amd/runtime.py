@@ -259,6 +259,101 @@ class FitnessEnsemble:
         return out
 
 
+def project_tokens(tokens, full_seq=None, n_std=20, n_special=11, u_special=None, n_max_mutations=None, keys=None):
+    """Token-level `Algo.project_sequences` (sampling/base.py:40-63), in place on
+    tokens (N, L) int64.  u_special (N, n_special) uniforms replace special tokens; keys (N, L) iid uniforms
+    pick which mutations survive the n_max_mutations cut.  Raises ValueError on a token outside the alphabet
+    or a special token with no u_special."""
+    dev = init(tokens.device if tokens.is_cuda else None)
+    lib = L.load()
+    assert tokens.dtype == torch.int64 and tokens.is_cuda and tokens.is_contiguous() and tokens.dim() == 2
+    N, Ls = tokens.shape
+    fs = None if full_seq is None else full_seq.to(dev, torch.int64).contiguous()
+    us = None if u_special is None else u_special.to(dev, torch.float32).contiguous()
+    ks = None if keys is None else keys.to(dev, torch.float32).contiguous()
+    if us is not None:
+        assert tuple(us.shape) == (N, n_special)
+    nm = -1 if n_max_mutations is None else int(n_max_mutations)
+    if nm >= 0:
+        assert fs is not None and ks is not None and tuple(ks.shape) == (N, Ls) and fs.numel() == Ls
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.sgpo_project_tokens(L.ptr(tokens), L.ptr(fs), N, Ls, n_std, n_special, L.ptr(us), nm, L.ptr(ks),
+                                    L.ptr(bad), L.stream_ptr()), 'sgpo_project_tokens')
+    b = int(bad.item())
+    if b & 1:
+        raise ValueError('token outside the alphabet')
+    if b & 2:
+        raise ValueError('special token in the batch and no u_special to replace it')
+    return tokens
+
+
+class AcquisitionSet:
+    """The sequence store of `ProteinPredictorDataset` (dataset/protein.py:41-44,153-183) as a hash set in HBM
+    (SURVEY.md section 8 row f-2).  `update` mirrors update_data's filter on a token batch."""
+
+    KEEP_ALL, NOT_IN_STORE, NOT_IN_ROUND = 0, 1, 2
+
+    def __init__(self, seq_len, capacity, max_batch, device=None):
+        self.device = init(device)
+        self.lib = L.load()
+        self.seq_len, self.capacity, self.max_batch = int(seq_len), int(capacity), int(max_batch)
+        h = C.c_void_p()
+        L.check(self.lib.sgpo_acq_create(self.seq_len, self.capacity, self.max_batch, C.byref(h)), 'sgpo_acq_create')
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.sgpo_acq_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def __len__(self):
+        return int(self.lib.sgpo_acq_count(self.handle))
+
+    def update(self, tokens, n_needed, scope, round=0):
+        """tokens (N, L) int64 on the device.  Returns (kept_idx (n_kept,) int64 batch rows appended, in batch
+        order; n_admissible = rows that passed the filter before the n_needed cut)."""
+        N = int(tokens.shape[0])
+        if N == 0:
+            return torch.empty(0, dtype=torch.int64, device=self.device), 0
+        assert tokens.dtype == torch.int64 and tokens.is_cuda and tokens.shape[1] == self.seq_len
+        tokens = tokens.contiguous()
+        kept = torch.empty(N, dtype=torch.int64, device=self.device)
+        nk, na = C.c_int(0), C.c_int(0)
+        L.check(self.lib.sgpo_acq_update(self.handle, L.ptr(tokens), N, int(n_needed), int(scope), int(round),
+                                         L.ptr(kept), C.byref(nk), C.byref(na), L.stream_ptr()), 'sgpo_acq_update')
+        return kept[:nk.value], na.value
+
+    def read(self, first=0, count=None):
+        """(tokens (count, L) int64, rounds (count,) int32) of store rows [first, first+count)."""
+        n = len(self)
+        count = n - first if count is None else count
+        tok = torch.empty(count, self.seq_len, dtype=torch.int64, device=self.device)
+        rnd = torch.empty(count, dtype=torch.int32, device=self.device)
+        L.check(self.lib.sgpo_acq_read(self.handle, first, count, L.ptr(tok), L.ptr(rnd), L.stream_ptr()), 'sgpo_acq_read')
+        return tok, rnd
+
+
+def landscape_lookup(table, tokens, residues, n_std=20):
+    """update_data's 4-site branch (dataset/protein.py:188-197): fitness of each row's combo from a dense
+    table (n_std ** n_res,) fp32; raises ValueError for a token outside the n_std letters."""
+    dev = init(tokens.device if tokens.is_cuda else None)
+    lib = L.load()
+    tokens = tokens.to(dev, torch.int64).contiguous()
+    table = table.to(dev, torch.float32).contiguous()
+    res = torch.as_tensor(residues, dtype=torch.int32).to(dev).contiguous()
+    N, Ls = tokens.shape
+    out = torch.empty(N, dtype=torch.float32, device=dev)
+    bad = torch.zeros(1, dtype=torch.int32, device=dev)
+    L.check(lib.sgpo_landscape_lookup(L.ptr(table), table.numel(), L.ptr(tokens), N, Ls, L.ptr(res), res.numel(), n_std,
+                                      L.ptr(out), L.ptr(bad), L.stream_ptr()), 'sgpo_landscape_lookup')
+    if int(bad.item()):
+        raise ValueError('token outside the standard alphabet')
+    return out
+
+
 class NoiseSource:
     """Counter-based noise bookkeeping: one (seed, call offset) pair per sampling kernel call.
 

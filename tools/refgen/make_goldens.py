@@ -466,7 +466,177 @@ def gen_oracle_ens():
         sys.modules.update(saved)
 
 
-GENS = dict(oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
+def gen_acquire():
+    """f-2: the reference's own Algo.project_sequences (sampling/base.py:40-63) and
+    ProteinPredictorDataset.update_data (dataset/protein.py:153-213) on scripted inputs.  numpy's
+    random.choice is replaced, for the duration of the projection calls, by a reader of the noise arrays the
+    restatement and the kernel take (u_special, keys); everything else is the reference's code."""
+    import json
+    import types
+    from sampling.base import Algo
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('acq_port', os.path.join(ROOT, 'oracle', 'acquisition.py'))
+    port = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(port)
+
+    class _A(Algo):
+        def inference(self, observation=None, num_samples=1, **kw):
+            raise NotImplementedError
+
+    rng = np.random.default_rng(5)
+    tok = standins.Tokenizer()
+    alpha = standins.ALPHABET
+    out = {}
+    for case, (L, N, n_max, p_special, p_mut) in dict(a=(24, 48, None, 0.08, 0.3), b=(24, 48, 3, 0.08, 0.3),
+                                                     c=(119, 32, 10, 0.01, 0.15), d=(119, 32, 200, 0.0, 0.5)).items():
+        full = rng.integers(0, 20, L)
+        x = np.tile(full, (N, 1))
+        mut = rng.random((N, L)) < p_mut
+        x[mut] = rng.integers(0, 20, int(mut.sum()))
+        spec_m = rng.random((N, L)) < p_special
+        x[spec_m] = rng.integers(20, 31, int(spec_m.sum()))
+        x[0] = full                                                    # an untouched parent
+        u_special = rng.random((N, 11)).astype(np.float32)
+        keys = rng.random((N, L)).astype(np.float32)
+        keys[1, : L // 2] = 0.5                                        # ties: the smaller position wins
+        full_s = ''.join(alpha[t] for t in full)
+        dc = standins.to_attr(dict(alphabet=alpha, alphabet_size=31, seq_len=L, full_seq=full_s, residues=None))
+        algo = _A(net=types.SimpleNamespace(tokenizer=tok), data_config=dc, n_max_mutations=n_max, device='cpu')
+        seqs = [''.join(alpha[t] for t in row) for row in x]
+        # queue of step-1 draws: one per special character met while walking each original string
+        q1 = []
+        for n in range(N):
+            for j in range(L):
+                if x[n, j] >= 20:
+                    q1.append(alpha[min(int(np.float32(u_special[n, x[n, j] - 20]) * np.float32(20)), 19)])
+        state = dict(i1=0, n2=0)
+
+        def choice(a, size=None, replace=True, p=None):
+            if size is None:                                           # base.py:47
+                assert list(a) == list(alpha[:20])
+                v = q1[state['i1']]
+                state['i1'] += 1
+                return v
+            assert replace is False                                    # base.py:55
+            n = state['n2']
+            state['n2'] += 1
+            return np.array(sorted(list(a), key=lambda j: (float(keys[n, j]), j))[:size], dtype=np.int64)
+        orig = np.random.choice
+        np.random.choice = choice
+        try:
+            res = algo.project_sequences(seqs)
+        finally:
+            np.random.choice = orig
+        assert state['i1'] == len(q1) and state['n2'] == (N if n_max is not None else 0)
+        y = np.array([[tok.a_to_i[c] for c in r] for r in res])
+        mine = port.project_tokens(x, full, 20, u_special, n_max, keys)
+        assert np.array_equal(mine, y), case
+        out.update({f'{case}_x': x, f'{case}_full': full, f'{case}_u_special': u_special, f'{case}_keys': keys,
+                    f'{case}_n_max': -1 if n_max is None else n_max, f'{case}_y': y})
+        print('  project case', case, 'changed rows', int((y != x).any(axis=1).sum()), 'restatement == reference')
+    save('acquire_project', **out)
+
+    # ---- update_data: the reference's class, built without its __init__ (no csv / fasta / oracle files) ----
+    saved = {k: v for k, v in sys.modules.items() if k == 'oracle' or k.startswith('oracle.')}
+    for k in saved:
+        del sys.modules[k]
+    try:
+        pkg = types.ModuleType('oracle')
+        pkg.__path__ = [os.path.join(REF, 'oracle')]
+        sys.modules['oracle'] = pkg
+        bio = standins._mod('Bio')
+        bio.SeqIO = standins._mod('Bio.SeqIO')
+        standins._mod('wandb')
+        import pandas as pd
+        import dataset.protein as dp
+        dp.inference_oracle = lambda combos, protein=None, model_path=None: (None, torch.zeros(len(combos)))
+
+        def new_ds(n_res, L, df=None):
+            ds = object.__new__(dp.ProteinPredictorDataset)
+            ds.seqs = ds.round_seqs = ds.y = ds.summary_df = None
+            ds.round = 0
+            ds.residues = list(range(L)) if n_res == L else [1, 3, 4, 6]
+            ds.n_residues = n_res
+            ds.df = df
+            ds.data_config = types.SimpleNamespace(name='CreiLOV', oracle_model_path='unused')
+            return ds
+
+        def pool(n, L, n_distinct):
+            base = [''.join(alpha[t] for t in rng.integers(0, 20, L)) for _ in range(n_distinct)]
+            return [base[i] for i in rng.integers(0, n_distinct, n)]
+
+        scenarios = {}
+        L = 12
+        scripts = dict(
+            round_scope=[dict(n=40, distinct=25, n_needed=100, BO=False, round=0, unique_only=True),
+                         dict(n=40, distinct=25, n_needed=100, BO=False, round=0, unique_only=True),
+                         dict(n=40, distinct=30, n_needed=5, BO=False, round=0, unique_only=True),
+                         dict(n=40, distinct=25, n_needed=100, BO=False, round=1, unique_only=True),
+                         dict(n=40, distinct=25, n_needed=100, BO=False, round=1, unique_only=True),
+                         dict(n=0, distinct=1, n_needed=10, BO=False, round=1, unique_only=True)],
+            bo=[dict(n=30, distinct=20, n_needed=100, BO=True, round=0, unique_only=True),
+                dict(n=30, distinct=20, n_needed=100, BO=True, round=0, unique_only=True),
+                dict(n=30, distinct=20, n_needed=100, BO=True, round=1, unique_only=True),
+                dict(n=30, distinct=28, n_needed=4, BO=True, round=2, unique_only=True),
+                dict(n=30, distinct=28, n_needed=100, BO=True, round=2, unique_only=True)],
+            keep_duplicates=[dict(n=20, distinct=8, n_needed=100, BO=False, round=0, unique_only=False),
+                             dict(n=20, distinct=8, n_needed=100, BO=False, round=0, unique_only=False),
+                             dict(n=20, distinct=8, n_needed=7, BO=False, round=1, unique_only=False)],
+            empty_first=[dict(n=0, distinct=1, n_needed=10, BO=True, round=0, unique_only=True),
+                         dict(n=16, distinct=6, n_needed=100, BO=True, round=0, unique_only=True)])
+        shared = pool(200, L, 60)                                      # calls draw from one pool: overlaps across calls
+        for name, script in scripts.items():
+            ds = new_ds(L, L)
+            mine = port.SequenceStore()
+            calls = []
+            for c in script:
+                batch = [shared[i] for i in rng.integers(0, c['distinct'] * 2, c['n'])]
+                before = 0 if ds.seqs is None else len(ds.seqs)
+                ret = ds.update_data(list(batch), c['n_needed'], BO=c['BO'], round=c['round'], unique_only=c['unique_only'])
+                added = list(ds.seqs[before:])
+                assert ret == len(added)
+                idx, adm = mine.update(batch, c['n_needed'], BO=c['BO'], round=c['round'], unique_only=c['unique_only'])
+                assert len(idx) == len(added), (name, len(idx), len(added))
+                if adm <= c['n_needed']:
+                    assert sorted(batch[i] for i in idx) == sorted(added), name
+                calls.append(dict(batch=batch, n_needed=c['n_needed'], BO=c['BO'], round=c['round'],
+                                  unique_only=c['unique_only'], ref_added_sorted=sorted(added), ref_returned=ret,
+                                  truncated=bool(adm > c['n_needed'])))
+                if adm > c['n_needed']:
+                    # keep both stores identical from here on: adopt the reference's choice
+                    mine.seqs = list(ds.seqs)
+                    mine.round_seqs = list(ds.round_seqs)
+                    calls[-1]['ref_added_in_order'] = added
+            scenarios[name] = calls
+            print('  update scenario', name, [c['ref_returned'] for c in calls], 'restatement == reference (as sets)')
+        # landscape branch (n_residues == 4): fitness looked up in the data frame, 0 when missing
+        combos = [''.join(alpha[t] for t in rng.integers(0, 20, 4)) for _ in range(50)]
+        df = pd.DataFrame({'Combo': combos[:40], 'fitness': rng.random(40).astype(np.float32)})
+        df = df.drop_duplicates('Combo')
+        ds = new_ds(4, 8, df)
+        parent = ''.join(alpha[t] for t in rng.integers(0, 20, 8))
+        seqs = []
+        for cmb in combos:
+            sq = list(parent)
+            for k, r in enumerate(ds.residues):
+                sq[r] = cmb[k]
+            seqs.append(''.join(sq))
+        import io
+        import contextlib
+        with contextlib.redirect_stdout(io.StringIO()):
+            ds.update_data(seqs, 1000)
+        scenarios['landscape'] = dict(seqs=seqs, residues=ds.residues, combos=list(df['Combo']),
+                                      fitness=[float(v) for v in df['fitness']], y=[float(v) for v in ds.y])
+        with open(os.path.join(OUT, 'acquire_update.json'), 'w') as f:
+            json.dump(scenarios, f)
+        print('acquire_update.json: %.1f KiB' % (os.path.getsize(os.path.join(OUT, 'acquire_update.json')) / 1024))
+    finally:
+        for k in [k for k in sys.modules if k == 'oracle' or k.startswith('oracle.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+
+
+GENS = dict(acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
