@@ -140,16 +140,20 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr int PH = CFG::PH, KP = KK / PH;
   constexpr bool RES = (EPI == EPI_GATE_RES || EPI == EPI_RES);
   constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
-  constexpr bool CAN_EXACT = !F32OUT;   // a full-tile epilogue leaves exactly E_ST stores in flight
+  // fp32 output on the 256x256 tile goes out like the fp32 residual: staged through LDS, whole lines (N % 256 == 0)
+  constexpr bool F32ST = F32OUT && MT * NT * 4 > 16;
+  constexpr bool CAN_EXACT = !F32OUT || F32ST;   // a full-tile epilogue leaves exactly E_ST stores in flight
   // store instructions per wave in a full-tile epilogue: bf16 tiles go out as whole 128-B lines (4 per 32 rows)
   // PRE: the fp32 residual tile fits in 16 float4 registers and is prefetched one K-step ahead (CfgRes);
   // otherwise (CfgBig) the residual is loaded inside the epilogue, block by block, in whole lines
   constexpr bool PRE = RES && MT * NT * 4 <= 16;
-  constexpr int E_ST = (PRE || F32OUT) ? MT * NT * 4 : RES ? MT * 8 : MT * 4;
+  constexpr bool STAGED32 = (RES && !PRE) || F32ST;
+  constexpr bool HAS_X = RES || EPI == EPI_ACC_F32;   // the epilogue adds what the output location holds / xin
+  constexpr int E_ST = STAGED32 ? MT * 8 : (PRE || F32OUT) ? MT * NT * 4 : MT * 4;
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
   static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
-  static_assert(!RES || PRE || (A_PW >= 4 && B_PW >= 4), "fp32 output staging: 32 x 64 block = two 4-KiB halves");
+  static_assert(!STAGED32 || (A_PW >= 4 && B_PW >= 4), "fp32 output staging: 32 x 64 block = two 4-KiB halves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -181,7 +185,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   };
 
   // ---- aux tables -> LDS (once per launch; the only ordinary loads outside RES / fp32-out epilogues)
-  if constexpr (!F32OUT) {
+  if constexpr (!F32OUT || F32ST) {
     if constexpr (EPI == EPI_QKV_ROPE) {
       if constexpr (ROPE_LDS) {
         const int n = p.L * (p.head_dim / 2);
@@ -318,14 +322,16 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   auto res_block = [&](int m_blk, int nb0, uint32_t h0, uint32_t h1, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const int r4 = lane >> 4, c16 = lane & 15;
-    const float* xp = p.xin + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
     float* cp = reinterpret_cast<float*>(p.C) + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
-    f32x4_t xr[8];
+    const float* xp = (RES ? p.xin : reinterpret_cast<const float*>(p.C)) + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
+    f32x4_t xr[HAS_X ? 8 : 1];
+    if constexpr (HAS_X) {
 #pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      size_t ro = (size_t)(i * 4) * p.ldc;
-      if (!FULL && m_blk + i * 4 + r4 > p.M - 1) ro = 0;   // any valid row: the value is not stored
-      xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xp + ro));
+      for (int i = 0; i < 8; ++i) {
+        size_t ro = (size_t)(i * 4) * p.ldc;
+        if (!FULL && m_blk + i * 4 + r4 > p.M - 1) ro = 0;   // any valid row: the value is not stored
+        xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xp + ro));
+      }
     }
     const uint32_t k0 = r4 * 256 + ((c16 ^ r4) << 4), k1 = r4 * 256 + ((c16 ^ (r4 + 4)) << 4);
 #pragma unroll
@@ -336,8 +342,11 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int i = hf * 4 + j;
-        const f32x4_t x4 = xr[i];
-        const f32x4_t v = {rn_add(x4.x, o[j].x), rn_add(x4.y, o[j].y), rn_add(x4.z, o[j].z), rn_add(x4.w, o[j].w)};
+        f32x4_t v = o[j];
+        if constexpr (HAS_X) {
+          const f32x4_t x4 = xr[i];
+          v = f32x4_t{rn_add(x4.x, o[j].x), rn_add(x4.y, o[j].y), rn_add(x4.z, o[j].z), rn_add(x4.w, o[j].w)};
+        }
         if (FULL || m_blk + i * 4 + r4 < p.M) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc));
       }
     }
@@ -346,7 +355,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   auto epilogue = [&](int m0, int n0, int fslot, auto full_tag) {
     constexpr bool FULL = decltype(full_tag)::value;
     const int nb0 = n0 + wn * NT * 32;
-    if (!FULL && !F32OUT && nb0 >= p.N) return;   // wave-uniform: this wave's 64 columns lie outside N
+    if (!FULL && !(F32OUT && !F32ST) && nb0 >= p.N) return;   // wave-uniform: this wave's 64 columns lie outside N
     if constexpr (EPI == EPI_QKV_ROPE) {
       const bool rope = nb0 < p.rope_cols;  // wave-uniform: the 64 columns are one head of q, k or v
       const int hd2 = p.head_dim / 2;
@@ -392,7 +401,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         store_block(pk, m_blk, nb0, fslot, full_tag);
         __builtin_amdgcn_sched_barrier(0);   // one block at a time: keeps the epilogue's register peak down
       }
-    } else if constexpr (F32OUT) {
+    } else if constexpr (F32OUT && !F32ST) {
       float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
@@ -412,7 +421,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
               }
           }
       }
-    } else if constexpr (RES && !PRE) {
+    } else if constexpr (STAGED32) {
       char* fs = smem + fslot * STAGE;
       const uint32_t h0 = lds_addr(fs + (wave * A_PW) * 1024);
       const uint32_t h1 = lds_addr(fs + A_BYTES + (wave * B_PW) * 1024);
@@ -566,7 +575,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // so the two waves of a SIMD share the VALU for their epilogues instead of running them one after
   // the other.  Both orders put the stores between stage(e+D) and stage(e+1+D) in the wave's VM queue
   // (e = last step of the tile), so the wait counts below are the same for both groups.
-  constexpr bool EARLY1 = !PRE && !F32OUT;
+  constexpr bool EARLY1 = !PRE && (!F32OUT || F32ST);
   for (int ti = 0; ti < n_my; ++ti) {
     STAMP(7);
     if (ti > 0 && !(EARLY1 && grp == 1)) {
@@ -695,7 +704,7 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   if (EPI == EPI_QKV_ROPE) {
     aux = (size_t)q.L * q.head_dim * sizeof(float);   // cos + sin
     if (!ROPE_LDS) { aux = 0; flags = 0; }           // table read from global: ordinary loads, drained waits
-  } else if (!F32OUT) {
+  } else if (!F32OUT || CFG::MT * CFG::NT * 4 > 16) {
     aux = (size_t)q.N * sizeof(float);
   }
   if (RING + aux > LDS_MAX_BYTES) return SGPO_ERR_UNSUPPORTED;
@@ -749,7 +758,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #endif
   GemmParams q = p;
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
-  const bool big = !f32out && tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096;
+  const bool big = tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096 && p.ldc % 4 == 0;
   ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
 #define LAUNCH_BOTH(E)                                                              \
@@ -772,8 +781,8 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
     LAUNCH_RES(EPI_BIAS_GELU_ERF)   // erff needs too many registers beside the 256x256 accumulators
     LAUNCH_BOTH(EPI_GATE_RES)
     LAUNCH_BOTH(EPI_RES)
-    LAUNCH_RES(EPI_BIAS_F32)
-    LAUNCH_RES(EPI_ACC_F32)
+    LAUNCH_BOTH(EPI_BIAS_F32)
+    LAUNCH_RES(EPI_ACC_F32)    // the staged form spills beside the 256x256 accumulators; unused on the hot paths
     default: break;
   }
 #undef LAUNCH_BOTH

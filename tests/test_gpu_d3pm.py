@@ -90,6 +90,22 @@ def test_bytenet_forward_vs_oracle(rt, cfg, B, L):
     assert (got - ref).abs().max() / ref.abs().max() < 3e-2
 
 
+def test_bytenet_forward_large_batch_matches_small_batch(rt):
+    """M = 13 x 389 = 5057 rows: every GEMM (1x1, dilated conv, fp32 output and fp32 residual) takes the 256x256
+    tile of the persistent kernel with a ragged last tile; a sequence's logits must not depend on the batch it
+    is in (the 3-sequence batch runs the 256x128 tile)."""
+    from sgpo_amd import weights as W
+    sd = W.bytenet_synthetic_state(seed=5, n_layers=9)
+    net = rt.BytenetDenoiser(sd)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randint(0, S, (13, 389), generator=g).cuda()
+    tt = torch.randint(1, 500, (13,), generator=g).cuda()
+    big, hbig = net.forward(x, tt, return_hidden=True)
+    for sl in (slice(0, 3), slice(10, 13)):
+        small, hsmall = net.forward(x[sl].contiguous(), tt[sl].contiguous(), return_hidden=True)
+        assert torch.equal(hsmall, hbig[sl]) and torch.equal(small, big[sl])
+
+
 def _mh_setup(rt, g):
     from sgpo_amd import weights as W
     res1 = [int(r) for r in g['residues']]
