@@ -287,6 +287,28 @@ def main():
         acq = dict(workload='project_tokens (n_max_mutations 10) + acquisition-set update (BO scope), %d x %d tokens' % (B, Lx),
                    ms=round(ams, 3), sequences_per_s=round(B / (ams * 1e-3), 1), appended_per_call=kept_total / reps,
                    note='wall clock incl. the two host synchronisations of sgpo_acq_update')
+    # row f-3: value-function ensemble training (10 members in lockstep, batch 64), outside the headline region
+    trn = None
+    if rank == 0:
+        from sgpo_amd import runtime as rt
+        from sgpo_amd import weights as W
+        E_m, B_t, n_steps = 10, 64, 100
+        trainer = rt.MlpEnsembleTrainer([W.mlp_synthetic_state(seed=50 + e, n_residues=119) for e in range(E_m)], list(range(119)),
+                                        device=device)
+        gen = torch.Generator(device=device).manual_seed(4)
+        xtr = torch.randint(0, 31, (E_m, B_t, 119), device=device, generator=gen)
+        ttr = torch.randint(0, T_STEPS, (E_m, B_t), device=device, generator=gen).float()
+        ytr = torch.randn(E_m, B_t, device=device, generator=gen)
+        for _ in range(5):
+            trainer.step(xtr, ttr, ytr)
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        for _ in range(n_steps):
+            trainer.step(xtr, ttr, ytr)
+        torch.cuda.synchronize()
+        tms = (time.perf_counter() - t2) * 1e3 / n_steps
+        trn = dict(workload='Adam/MSE step of MLPModel (119 residues, 510 k parameters), %d members in lockstep, batch %d' % (E_m, B_t),
+                   ms_per_step=round(tms, 4), member_steps_per_s=round(E_m / (tms * 1e-3), 1))
     if rank == 0:
         cpu = None
         if not a.no_cpu_baseline:
@@ -301,7 +323,7 @@ def main():
                        'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate',
                        'value_function': 'MLPModel hidden 64, fp32', 'global_batch': world * B,
                        'parallelism': f'dp{world} (independent shards + all-gather of tokens/scores)'},
-            'roofline': roof, 'cpu_baseline': cpu, 'fitness_ensemble': fit, 'acquisition': acq, 'kernels': kernels,
+            'roofline': roof, 'cpu_baseline': cpu, 'fitness_ensemble': fit, 'acquisition': acq, 'ensemble_training': trn, 'kernels': kernels,
         }
         print(json.dumps(line))
     if world > 1:

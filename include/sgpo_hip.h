@@ -196,6 +196,25 @@ int sgpo_acq_read(const sgpo_acq* a, long long first, long long count, int64_t* 
 int sgpo_landscape_lookup(const float* table, size_t table_len, const int64_t* tokens, int N, int L,
                           const int* residues, int n_res, int n_std, float* out, int* bad_flag, void* stream);
 
+/* ---- value-function ensemble training: training/train_classifier.py:7-64 ----
+ * Adam (torch.optim.Adam defaults, train_classifier.py:23) on MSELoss (train_classifier.py:24) of MLPModel
+ * (problem/protein.py:58-121), n_members models advanced in lockstep: one call = one optimiser step of
+ * train_step (train_classifier.py:7-19) for every member on that member's own batch.
+ * blobs (fp32, device) [n_members][P], P = sgpo_mlp_trainer_param_count(...), each in the order of sgpo_mlp_create;
+ * read_pos as there (HOST int32).  The caller draws t, applies q_sample and project_fn (train_classifier.py:13-14)
+ * and passes the result: x [n_members][B][L] int64, t [n_members][B] fp32 (NULL when not time-conditioned),
+ * y [n_members][B] fp32, 1 <= B <= 64.  loss_out [n_members] (device) = the step's MSE before the update.
+ * GaussianFourierProjection.W is not trained (requires_grad=False, protein.py:52).  Every reduction runs in a
+ * fixed order: the same inputs give the same bits. */
+typedef struct sgpo_mlp_trainer sgpo_mlp_trainer;
+size_t sgpo_mlp_trainer_param_count(int n_read, int alphabet, int time_conditioned);
+int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_read, const int* read_pos, int alphabet,
+                            int hidden, int time_conditioned, sgpo_mlp_trainer** out);
+void sgpo_mlp_trainer_destroy(sgpo_mlp_trainer* t);
+int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L,
+                          double lr, double beta1, double beta2, double eps, float* loss_out, void* stream);
+int sgpo_mlp_trainer_read(const sgpo_mlp_trainer* t, float* blobs_out, void* stream);
+
 /* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb
  * (dit.py:494-515: mean-pool over L + Linear(hidden, 1); w_cls = its weight, [hidden] fp32).
  * One backbone pass, then num_nos_steps closed-form gradient + Adagrad updates of delta

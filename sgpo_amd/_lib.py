@@ -57,6 +57,11 @@ SIGNATURES = {
     'sgpo_acq_update': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, C.POINTER(_i), C.POINTER(_i), _vp]),
     'sgpo_acq_read': (_i, [_vp, C.c_longlong, C.c_longlong, _vp, _vp, _vp]),
     'sgpo_landscape_lookup': (_i, [_vp, _sz, _vp, _i, _i, _vp, _i, _i, _vp, _vp, _vp]),
+    'sgpo_mlp_trainer_param_count': (_sz, [_i, _i, _i]),
+    'sgpo_mlp_trainer_create': (_i, [_vp, _i, _i, C.POINTER(_i), _i, _i, _i, C.POINTER(_vp)]),
+    'sgpo_mlp_trainer_destroy': (None, [_vp]),
+    'sgpo_mlp_trainer_step': (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp]),
+    'sgpo_mlp_trainer_read': (_i, [_vp, _vp, _vp]),
     'sgpo_nos_workspace_bytes': (_sz, [_vp, _i, _i]),
     'sgpo_nos_denoise': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _u64, _u64, _u64,
                               _vp, _vp, _vp, _vp, _vp, _sz, _vp, _sz, _vp]),

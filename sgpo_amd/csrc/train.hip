@@ -1,0 +1,449 @@
+// Row f-3: value-function ensemble training (training/train_classifier.py:7-64 -- Adam on the MSE of
+// MLPModel, problem/protein.py:58-121), all ensemble members in lockstep, five launches per optimiser step.
+//   tr_fwd0   grid (chunks, members): one 64-wide input chunk (a residue's embedding, or the time embedding)
+//             times its slice of mlp.0.weight -> partial pre-activations
+//   tr_reduce grid over (member, row, unit): ordered sum of the partials + bias
+//   tr_mid    grid (members): the four 64x64 layers + head forward, MSE, and the
+//             backward pass down to d(pre-activation of mlp.0); activations live in LDS
+//   tr_bwd0   grid (chunks, members): gradient of the mlp.0.weight slice, of the chunk's input, and through the
+//             embedder (per-chunk partial sums per token) or the time embedder
+//   tr_adam   grid over all parameters: ordered sum of the embedder partials, torch.optim.Adam's update
+// fp32 throughout, every reduction in a fixed order (no atomics): a run is reproducible bit for bit.
+#include "common.h"
+#include <new>
+
+namespace {
+
+constexpr int H = 64;          // hidden_dim (problem/protein.py: 64)
+constexpr int TB = 64;         // largest batch of one step (configs/problem/protein_classifier_discrete.yaml: 64)
+constexpr int PAD = H + 1;
+
+struct TrDev {
+  float* params;   // [E][P]
+  float* grads;    // [E][P]
+  float* m;        // [E][P]
+  float* v;        // [E][P]
+  float* part_h;   // [E][C][TB][H]
+  float* dh;       // [E][TB][H]
+  float* fbuf;     // [E][TB][H]   Fourier features of t
+  float* part_e;   // [E][n_read][32][H]   rows 0..A-1: d embedder.weight[:, s], row 31: d embedder.bias
+  const int* read_pos;
+  int E, P, C, n_read, A, D, time_cond;
+  // offsets into one member's blob (MLP_ORDER of sgpo_amd/runtime.py)
+  int o_tw, o_t1w, o_t1b, o_ew, o_eb, o_w0, o_b0, o_w1, o_b1, o_w2, o_b2, o_c0, o_c0b, o_c2, o_c2b;
+};
+
+// in[b][k] of chunk c: embedding of the token at read position c, or the time embedding (c == n_read)
+__device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const int64_t* x, const float* t, int B, int L,
+                            float (*in)[PAD], float (*tmp)[PAD], bool write_f) {
+  const int tid = threadIdx.x;
+  if (c < d.n_read) {
+    const float* ew = p + d.o_ew;
+    const float* eb = p + d.o_eb;
+    const int pos = d.read_pos[c];
+    for (int idx = tid; idx < TB * H; idx += 256) {
+      const int b = idx >> 6, k = idx & 63;
+      float v = 0.f;
+      if (b < B) {
+        int tok = (int)x[((size_t)e * B + b) * L + pos];
+        tok = tok < 0 ? 0 : (tok >= d.A ? d.A - 1 : tok);
+        v = ew[k * d.A + tok] + eb[k];
+      }
+      in[b][k] = v;
+    }
+  } else {
+    const float* tw = p + d.o_tw;
+    for (int idx = tid; idx < TB * H; idx += 256) {
+      const int b = idx >> 6, j = idx & 63;
+      float f = 0.f;
+      if (b < B) {
+        // GaussianFourierProjection (problem/protein.py:54-56): x*W*2*pi, cat(sin, cos)
+        const float arg = t[(size_t)e * B + b] * tw[j & 31] * 2.0f * 3.14159274101257324f;
+        f = (j < 32) ? sinf(arg) : cosf(arg);
+        if (write_f) d.fbuf[((size_t)e * TB + b) * H + j] = f;
+      }
+      tmp[b][j] = f;
+    }
+    __syncthreads();
+    const float* w = p + d.o_t1w;
+    const float* bb = p + d.o_t1b;
+    for (int idx = tid; idx < TB * H; idx += 256) {
+      const int b = idx >> 6, j = idx & 63;
+      float acc = 0.f;
+      if (b < B) {
+        acc = bb[j];
+        for (int k = 0; k < H; ++k) acc = fmaf(w[j * H + k], tmp[b][k], acc);
+      }
+      in[b][j] = acc;
+    }
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_fwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
+  __shared__ float in[TB][PAD], ws[H][PAD];
+  const int c = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+  const float* p = d.params + (size_t)e * d.P;
+  chunk_input(d, p, e, c, x, t, B, L, in, ws, true);
+  __syncthreads();
+  const float* w0 = p + d.o_w0 + (size_t)c * H;
+  for (int idx = tid; idx < H * H; idx += 256) ws[idx >> 6][idx & 63] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
+  __syncthreads();
+  const int o = tid & 63, bg = tid >> 6;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int k = 0; k < H; ++k) {
+    const float w = ws[o][k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[bg * 16 + j][k], w, acc[j]);
+  }
+  float* out = d.part_h + (((size_t)e * d.C + c) * TB) * H;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) out[(bg * 16 + j) * H + o] = acc[j];
+}
+
+// ordered sum of the chunk partials + bias -> pre-activation of mlp.0 (written over chunk 0's slot)
+__global__ void tr_reduce(TrDev d, int B) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (e, b, o)
+  if (i >= d.E * TB * H) return;
+  const int e = i / (TB * H), bo = i % (TB * H), b = bo >> 6, o = bo & 63;
+  if (b >= B) return;
+  float* ph = d.part_h + (size_t)e * d.C * TB * H;
+  float s = d.params[(size_t)e * d.P + d.o_b0 + o];
+  for (int c = 0; c < d.C; ++c) s += ph[(size_t)c * TB * H + bo];
+  ph[bo] = s;
+}
+
+// ---- block-level 64-wide layer helpers (256 threads, rows >= B hold zeros) ----
+__device__ void load_w(float (*wb)[PAD], const float* w) {
+  for (int idx = threadIdx.x; idx < H * H; idx += 256) wb[idx >> 6][idx & 63] = w[idx];
+  __syncthreads();
+}
+// out[b][o] = act(bias[o] + sum_k in[b][k] W[o][k]);  pre (optional) keeps the sign information for the backward pass
+__device__ void lin_fwd(float (*out)[PAD], float (*in)[PAD], float (*wb)[PAD], const float* bias, bool relu, int B) {
+  const int o = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  float acc[16];
+  const float bo = bias[o];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = bo;
+  for (int k = 0; k < H; ++k) {
+    const float w = wb[o][k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[bg * 16 + j][k], w, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int b = bg * 16 + j;
+    float v = acc[j];
+    if (relu) v = v > 0.f ? v : 0.f;
+    out[b][o] = b < B ? v : 0.f;
+  }
+  __syncthreads();
+}
+// dW[o][k] = sum_b dz[b][o] a[b][k];  db[o] = sum_b dz[b][o]
+__device__ void grad_w(float* dW, float* db, float (*dz)[PAD], float (*a)[PAD], int B) {
+  const int k = threadIdx.x & 63, og = threadIdx.x >> 6;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int b = 0; b < B; ++b) {
+    const float av = a[b][k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaf(dz[b][og * 16 + j], av, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dW[(og * 16 + j) * H + k] = acc[j];
+  if (threadIdx.x < H) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dz[b][threadIdx.x];
+    db[threadIdx.x] = s;
+  }
+}
+// da[b][k] = (sum_o dz[b][o] W[o][k]) * (mask ? act[b][k] > 0 : 1)
+__device__ void grad_in(float (*da)[PAD], float (*dz)[PAD], float (*wb)[PAD], float (*act)[PAD], bool relu_mask, int B) {
+  const int k = threadIdx.x & 63, bg = threadIdx.x >> 6;
+  float acc[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+  for (int o = 0; o < H; ++o) {
+    const float w = wb[o][k];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = fmaf(dz[bg * 16 + j][o], w, acc[j]);
+  }
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int b = bg * 16 + j;
+    float v = acc[j];
+    if (relu_mask && !(act[b][k] > 0.f)) v = 0.f;
+    da[b][k] = b < B ? v : 0.f;
+  }
+  __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__ y, int B, float* __restrict__ loss_out) {
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float (*a0)[PAD] = reinterpret_cast<float (*)[PAD]>(smem_raw);
+  float (*a1)[PAD] = a0 + TB;
+  float (*a2)[PAD] = a1 + TB;
+  float (*a3)[PAD] = a2 + TB;
+  float (*wb)[PAD] = a3 + TB;
+  float (*g0)[PAD] = wb + H;
+  float (*g1)[PAD] = g0 + TB;
+  float* pred = reinterpret_cast<float*>(g1 + TB);   // [TB]
+  float* dpred = pred + TB;                          // [TB]
+  const int e = blockIdx.x, tid = threadIdx.x;
+  const float* p = d.params + (size_t)e * d.P;
+  float* g = d.grads + (size_t)e * d.P;
+  // pre-activation of mlp.0 (tr_reduce left it in chunk 0's slot) -> ReLU
+  {
+    const float* ph = d.part_h + (size_t)e * d.C * TB * H;
+    for (int idx = tid; idx < TB * H; idx += 256) {
+      const int b = idx >> 6, o = idx & 63;
+      float s = 0.f;
+      if (b < B) {
+        s = ph[idx];
+        s = s > 0.f ? s : 0.f;
+      }
+      a0[b][o] = s;
+    }
+    __syncthreads();
+  }
+  load_w(wb, p + d.o_w1); lin_fwd(a1, a0, wb, p + d.o_b1, true, B);
+  load_w(wb, p + d.o_w2); lin_fwd(a2, a1, wb, p + d.o_b2, false, B);
+  load_w(wb, p + d.o_c0); lin_fwd(a3, a2, wb, p + d.o_c0b, true, B);
+  // head + MSE (criterion = MSELoss(): mean over the batch)
+  const float* c2 = p + d.o_c2;
+  if (tid < TB) {
+    float s = 0.f, dp = 0.f;
+    if (tid < B) {
+      s = p[d.o_c2b];
+      for (int k = 0; k < H; ++k) s = fmaf(a3[tid][k], c2[k], s);
+      dp = 2.0f * (s - y[(size_t)e * B + tid]) / (float)B;
+    }
+    pred[tid] = s;
+    dpred[tid] = dp;
+  }
+  __syncthreads();
+  if (tid == 0) {
+    float l = 0.f;
+    for (int b = 0; b < B; ++b) { const float r = pred[b] - y[(size_t)e * B + b]; l += r * r; }
+    loss_out[e] = l / (float)B;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += dpred[b];
+    g[d.o_c2b] = s;
+  }
+  if (tid < H) {   // d cls_head.2.weight
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s = fmaf(dpred[b], a3[b][tid], s);
+    g[d.o_c2 + tid] = s;
+  }
+  // dz3[b][k] = dpred[b] * c2[k] * (a3 > 0)
+  for (int idx = tid; idx < TB * H; idx += 256) {
+    const int b = idx >> 6, k = idx & 63;
+    g0[b][k] = (b < B && a3[b][k] > 0.f) ? dpred[b] * c2[k] : 0.f;
+  }
+  __syncthreads();
+  grad_w(g + d.o_c0, g + d.o_c0b, g0, a2, B);          // cls_head.0
+  load_w(wb, p + d.o_c0); grad_in(g1, g0, wb, a2, false, B);   // d a2 (mlp.4 has no ReLU after it)
+  grad_w(g + d.o_w2, g + d.o_b2, g1, a1, B);           // mlp.4
+  load_w(wb, p + d.o_w2); grad_in(g0, g1, wb, a1, true, B);    // d z of mlp.2
+  grad_w(g + d.o_w1, g + d.o_b1, g0, a0, B);           // mlp.2
+  load_w(wb, p + d.o_w1); grad_in(g1, g0, wb, a0, true, B);    // d pre-activation of mlp.0
+  float* dh = d.dh + (size_t)e * TB * H;
+  for (int idx = tid; idx < TB * H; idx += 256) dh[idx] = g1[idx >> 6][idx & 63];
+  if (tid < H) {
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += g1[b][tid];
+    g[d.o_b0 + tid] = s;
+  }
+}
+
+__global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
+  __shared__ float in[TB][PAD], ws[H][PAD], dh[TB][PAD], dz[TB][PAD];
+  __shared__ int toks[TB];
+  const int c = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+  const float* p = d.params + (size_t)e * d.P;
+  float* g = d.grads + (size_t)e * d.P;
+  chunk_input(d, p, e, c, x, t, B, L, in, ws, false);   // for the time chunk ws holds the Fourier features meanwhile
+  __syncthreads();
+  if (c == d.n_read) {   // keep the Fourier features: dz of this chunk is d(time embedding)
+    for (int idx = tid; idx < TB * H; idx += 256) dz[idx >> 6][idx & 63] = ws[idx >> 6][idx & 63];
+    __syncthreads();
+  }
+  const float* w0 = p + d.o_w0 + (size_t)c * H;
+  const float* dhg = d.dh + (size_t)e * TB * H;
+  for (int idx = tid; idx < H * H; idx += 256) {
+    ws[idx >> 6][idx & 63] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
+    dh[idx >> 6][idx & 63] = dhg[idx];
+  }
+  if (tid < TB && c < d.n_read) {
+    int tok = 0;
+    if (tid < B) {
+      tok = (int)x[((size_t)e * B + tid) * L + d.read_pos[c]];
+      tok = tok < 0 ? 0 : (tok >= d.A ? d.A - 1 : tok);
+    }
+    toks[tid] = tok;
+  }
+  __syncthreads();
+  // d mlp.0.weight[o][c*64 + k] = sum_b dh[b][o] in[b][k]
+  {
+    const int k = tid & 63, og = tid >> 6;
+    float acc[16];
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float av = in[b][k];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = fmaf(dh[b][og * 16 + j], av, acc[j]);
+    }
+    float* gw = g + d.o_w0 + (size_t)c * H;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) gw[(size_t)(og * 16 + j) * d.D + k] = acc[j];
+  }
+  if (c < d.n_read) {
+    __syncthreads();
+    grad_in(dz, dh, ws, in, false, B);   // d(embedding of the token at this position)
+    // through the embedder: per-token sums in batch order (deterministic), bias = sum over the batch
+    float* pe = d.part_e + ((size_t)e * d.n_read + c) * 32 * H;
+    if (tid < H) {
+      float bsum = 0.f;
+      for (int s = 0; s < 31; ++s) in[s][tid] = 0.f;    // reuse `in` as the [token][k] accumulator (A <= 31)
+      for (int b = 0; b < B; ++b) {
+        const float v = dz[b][tid];
+        in[toks[b]][tid] += v;
+        bsum += v;
+      }
+      for (int s = 0; s < 31; ++s) pe[s * H + tid] = in[s][tid];
+      pe[31 * H + tid] = bsum;
+    }
+  } else {
+    // time chunk: dz holds the Fourier features f[b][k]; d temb[b][j] = sum_o dh[b][o] W0[o][j]
+    __syncthreads();
+    grad_in(in, dh, ws, in, false, B);   // in := d temb  (grad_in reads dh/ws only, then overwrites `in`)
+    grad_w(g + d.o_t1w, g + d.o_t1b, in, dz, B);
+  }
+}
+
+__global__ void tr_adam(TrDev d, float lr_over_bc1, float bc2_sqrt, float beta1, float beta2, float eps) {
+  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (i >= (size_t)d.E * d.P) return;
+  const int e = (int)(i / d.P), q = (int)(i % d.P);
+  if (q < d.o_t1w) return;   // GaussianFourierProjection.W: requires_grad=False
+  float gr;
+  if (q >= d.o_ew && q < d.o_b0 && q < d.o_w0) {
+    // embedder: ordered sum of the per-position partials
+    const float* pe = d.part_e + (size_t)e * d.n_read * 32 * H;
+    int row, k;
+    if (q < d.o_eb) { k = (q - d.o_ew) / d.A; row = (q - d.o_ew) % d.A; }
+    else { k = q - d.o_eb; row = 31; }
+    gr = 0.f;
+    for (int c = 0; c < d.n_read; ++c) gr += pe[((size_t)c * 32 + row) * H + k];
+  } else {
+    gr = d.grads[i];
+  }
+  // torch.optim.Adam (single-tensor path): exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
+  // value=1 - beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-step_size)
+  float m = d.m[i], v = d.v[i];
+  m = m + (gr - m) * (1.0f - beta1);
+  v = v * beta2 + (1.0f - beta2) * gr * gr;
+  d.m[i] = m;
+  d.v[i] = v;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  d.params[i] = d.params[i] - lr_over_bc1 * (m / denom);
+}
+
+}  // namespace
+
+struct sgpo_mlp_trainer {
+  TrDev d;
+  int* read_pos_dev;
+  long long step;
+  size_t mid_lds;
+};
+
+extern "C" size_t sgpo_mlp_trainer_param_count(int n_read, int alphabet, int time_conditioned) {
+  const size_t h = H, A = alphabet, D = h * (n_read + (time_conditioned ? 1 : 0));
+  return h / 2 + h * h + h + h * A + h + h * D + h + 3 * (h * h + h) + h + 1;
+}
+
+extern "C" void sgpo_mlp_trainer_destroy(sgpo_mlp_trainer* t) {
+  if (!t) return;
+  void* bufs[] = {t->d.params, t->d.grads, t->d.m, t->d.v, t->d.part_h, t->d.dh, t->d.fbuf, t->d.part_e, t->read_pos_dev};
+  for (void* b : bufs) (void)hipFree(b);
+  delete t;
+}
+
+extern "C" int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_read, const int* read_pos, int alphabet,
+                                       int hidden, int time_conditioned, sgpo_mlp_trainer** out) {
+  SGPO_REQUIRE(blobs && read_pos && out && n_members > 0 && n_read > 0, "mlp_trainer_create: bad arguments");
+  SGPO_REQUIRE(hidden == H, "mlp_trainer_create: hidden_dim %d unsupported (64 only)", hidden);
+  SGPO_REQUIRE(alphabet > 0 && alphabet <= 31, "mlp_trainer_create: alphabet %d (<= 31)", alphabet);
+  sgpo_mlp_trainer* t = new (std::nothrow) sgpo_mlp_trainer();
+  SGPO_REQUIRE(t, "mlp_trainer_create: out of host memory");
+  TrDev& d = t->d;
+  d = TrDev{};
+  t->read_pos_dev = nullptr;
+  d.E = n_members; d.n_read = n_read; d.A = alphabet; d.time_cond = time_conditioned ? 1 : 0;
+  d.C = n_read + d.time_cond;
+  d.D = H * d.C;
+  d.P = (int)sgpo_mlp_trainer_param_count(n_read, alphabet, time_conditioned);
+  int o = 0;
+  d.o_tw = o; o += H / 2;
+  d.o_t1w = o; o += H * H; d.o_t1b = o; o += H;
+  d.o_ew = o; o += H * alphabet; d.o_eb = o; o += H;
+  d.o_w0 = o; o += H * d.D; d.o_b0 = o; o += H;
+  d.o_w1 = o; o += H * H; d.o_b1 = o; o += H;
+  d.o_w2 = o; o += H * H; d.o_b2 = o; o += H;
+  d.o_c0 = o; o += H * H; d.o_c0b = o; o += H;
+  d.o_c2 = o; o += H; d.o_c2b = o; o += 1;
+  const size_t EP = (size_t)d.E * d.P;
+#define HIPF(e) do { hipError_t _e = (e); if (_e != hipSuccess) { sgpo_set_error("%s: %s", #e, hipGetErrorString(_e)); sgpo_mlp_trainer_destroy(t); return SGPO_ERR_HIP; } } while (0)
+  HIPF(hipMalloc((void**)&d.params, EP * 4));
+  HIPF(hipMalloc((void**)&d.grads, EP * 4));
+  HIPF(hipMalloc((void**)&d.m, EP * 4));
+  HIPF(hipMalloc((void**)&d.v, EP * 4));
+  HIPF(hipMalloc((void**)&d.part_h, (size_t)d.E * d.C * TB * H * 4));
+  HIPF(hipMalloc((void**)&d.dh, (size_t)d.E * TB * H * 4));
+  HIPF(hipMalloc((void**)&d.fbuf, (size_t)d.E * TB * H * 4));
+  HIPF(hipMalloc((void**)&d.part_e, (size_t)d.E * n_read * 32 * H * 4));
+  HIPF(hipMalloc((void**)&t->read_pos_dev, (size_t)n_read * sizeof(int)));
+  HIPF(hipMemcpy(t->read_pos_dev, read_pos, (size_t)n_read * sizeof(int), hipMemcpyHostToDevice));
+  d.read_pos = t->read_pos_dev;
+  HIPF(hipMemcpy(d.params, blobs, EP * 4, hipMemcpyDeviceToDevice));
+  HIPF(hipMemset(d.grads, 0, EP * 4));
+  HIPF(hipMemset(d.m, 0, EP * 4));
+  HIPF(hipMemset(d.v, 0, EP * 4));
+  t->step = 0;
+  t->mid_lds = (size_t)(4 * TB + H + 2 * TB) * PAD * 4 + 2 * TB * 4;
+  HIPF(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->mid_lds));
+#undef HIPF
+  *out = t;
+  return SGPO_OK;
+}
+
+extern "C" int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L,
+                                     double lr, double beta1, double beta2, double eps, float* loss_out, void* stream) {
+  SGPO_REQUIRE(t && x && y && loss_out, "mlp_trainer_step: null argument");
+  SGPO_REQUIRE(B > 0 && B <= TB, "mlp_trainer_step: batch %d outside 1..%d", B, TB);
+  SGPO_REQUIRE(!t->d.time_cond || tt, "mlp_trainer_step: a time-conditioned model needs t");
+  hipStream_t s = (hipStream_t)stream;
+  const TrDev& d = t->d;
+  hipLaunchKernelGGL(tr_fwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);
+  hipLaunchKernelGGL(tr_reduce, dim3((d.E * TB * H + 255) / 256), dim3(256), 0, s, d, B);
+  hipLaunchKernelGGL(tr_mid, dim3(d.E), dim3(256), t->mid_lds, s, d, y, B, loss_out);
+  hipLaunchKernelGGL(tr_bwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);
+  t->step += 1;
+  // torch/optim/adam.py _single_tensor_adam: the scalars are formed in double, applied to fp32 tensors
+  const double bc1 = 1.0 - pow(beta1, (double)t->step), bc2 = 1.0 - pow(beta2, (double)t->step);
+  const size_t n = (size_t)d.E * d.P;
+  hipLaunchKernelGGL(tr_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, (float)(lr / bc1), (float)sqrt(bc2),
+                     (float)beta1, (float)beta2, (float)eps);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+extern "C" int sgpo_mlp_trainer_read(const sgpo_mlp_trainer* t, float* blobs_out, void* stream) {
+  SGPO_REQUIRE(t && blobs_out, "mlp_trainer_read: null argument");
+  SGPO_CHECK_HIP(hipMemcpyAsync(blobs_out, t->d.params, (size_t)t->d.E * t->d.P * 4, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+  return SGPO_OK;
+}

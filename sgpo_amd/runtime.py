@@ -204,6 +204,70 @@ class MlpValueFunction:
         return out
 
 
+class MlpEnsembleTrainer:
+    """Adam/MSE training of an ensemble of MLPModel value functions in lockstep on the GPU
+    (training/train_classifier.py:7-64).  states: list of MLPModel state dicts."""
+
+    def __init__(self, states, read_pos, alphabet=31, hidden=64, time_conditioned=True, device=None):
+        self.device = init(device)
+        self.lib = L.load()
+        self.read_pos = [int(p) for p in read_pos]
+        self.n_members = len(states)
+        self.time_conditioned = bool(time_conditioned)
+        self._shapes = [(k, tuple(states[0][k].shape)) for k in MLP_ORDER]
+        blob = torch.stack([_blob(sd, MLP_ORDER, self.device) for sd in states]).contiguous()
+        self.n_params = blob.shape[1]
+        want = self.lib.sgpo_mlp_trainer_param_count(len(self.read_pos), alphabet, 1 if time_conditioned else 0)
+        if self.n_params != want:
+            raise L.SgpoError(f'MLPModel state dict has {self.n_params} parameters, the trainer expects {want}')
+        arr = (C.c_int * len(self.read_pos))(*self.read_pos)
+        h = C.c_void_p()
+        L.check(self.lib.sgpo_mlp_trainer_create(L.ptr(blob), self.n_members, len(self.read_pos), arr, alphabet, hidden,
+                                                 1 if time_conditioned else 0, C.byref(h)), 'sgpo_mlp_trainer_create')
+        self.handle = h
+
+    def __del__(self):
+        try:
+            if getattr(self, 'handle', None):
+                self.lib.sgpo_mlp_trainer_destroy(self.handle)
+                self.handle = None
+        except Exception:
+            pass
+
+    def step(self, x, t, y, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """One optimiser step for every member.  x (E, B, L) int64, t (E, B) or None, y (E, B); returns the
+        members' MSE losses (E,) on the device (before the update)."""
+        E, B, Lq = x.shape
+        assert E == self.n_members and tuple(y.shape) == (E, B)
+        if max(self.read_pos) >= Lq:
+            raise L.SgpoError(f'value function reads position {max(self.read_pos)} of a length-{Lq} sequence')
+        x = x.to(self.device, torch.int64).contiguous()
+        y = y.to(self.device, torch.float32).contiguous()
+        tt = None
+        if self.time_conditioned:
+            tt = t.to(self.device, torch.float32).contiguous()
+            assert tuple(tt.shape) == (E, B)
+        loss = torch.empty(E, dtype=torch.float32, device=self.device)
+        L.check(self.lib.sgpo_mlp_trainer_step(self.handle, L.ptr(x), L.ptr(tt), L.ptr(y), B, Lq, float(lr), float(betas[0]),
+                                               float(betas[1]), float(eps), L.ptr(loss), L.stream_ptr()), 'sgpo_mlp_trainer_step')
+        return loss
+
+    def state_dicts(self):
+        blob = torch.empty(self.n_members, self.n_params, dtype=torch.float32, device=self.device)
+        L.check(self.lib.sgpo_mlp_trainer_read(self.handle, L.ptr(blob), L.stream_ptr()), 'sgpo_mlp_trainer_read')
+        out = []
+        for e in range(self.n_members):
+            sd, o = {}, 0
+            for k, shp in self._shapes:
+                n = 1
+                for q in shp:
+                    n *= q
+                sd[k] = blob[e, o:o + n].reshape(shp).clone()
+                o += n
+            out.append(sd)
+        return out
+
+
 class FitnessEnsemble:
     """The fitness-oracle ensemble of oracle/inference_oracle.py on the GPU.
 

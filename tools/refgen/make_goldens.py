@@ -636,7 +636,92 @@ def gen_acquire():
         sys.modules.update(saved)
 
 
-GENS = dict(acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
+def gen_train():
+    """f-3: the reference's own train_classifier (training/train_classifier.py:21-64) on scripted batches.  The
+    diffusion model handed to it is a stub whose q_sample returns the pre-drawn noised batch of the step; the
+    timesteps it draws with torch.randint are reproduced by re-seeding torch before the call."""
+    import types
+    standins._mod('hydra')
+    hu = standins._mod('hydra.utils')
+    hu.instantiate = lambda *a, **k: None
+    sys.modules['hydra'].utils = hu
+    from training.train_classifier import train_classifier
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('oracle.train_mlp', os.path.join(ROOT, 'oracle', 'train_mlp.py'),
+                                                  submodule_search_locations=None)
+    import oracle.mlp  # noqa: F401  (this repo's test oracle package)
+    port = importlib.util.module_from_spec(spec)
+    port.__package__ = 'oracle'
+    spec.loader.exec_module(port)
+    out = {}
+    for case, (L, residues, tc, n, bs, epochs, T) in dict(full=(24, None, True, 150, 64, 2, 128),
+                                                         sites=(40, [3, 7, 8, 20, 33], True, 70, 32, 3, 128),
+                                                         clean=(24, None, False, 100, 64, 2, 128)).items():
+        g = torch.Generator().manual_seed(31 + L)
+        n_res = L if residues is None else len(residues)
+        clf, _ = build_ref_mlp(n_res, residues, 17, L)   # MLPModel keeps its time embedder either way (t = 0 when tc is off)
+        x = torch.randint(0, 20, (n, L), generator=g)
+        y = torch.randn(n, generator=g)
+        steps = []
+        for ep in range(epochs):
+            perm = torch.randperm(n, generator=g)
+            for i in range(0, n, bs):
+                idx = perm[i:i + bs]
+                xb = x[idx]
+                xt = torch.where(torch.rand(xb.shape, generator=g) < 0.3, torch.full_like(xb, 28), xb) if tc else xb
+                steps.append((xb, xt, y[idx]))
+
+        class _Model:
+            device = 'cpu'
+            timestep = T
+
+            def __init__(self):
+                self.i = 0
+
+            def q_sample(self, xb, t):
+                xt = steps[self.i][1]
+                assert torch.equal(xb, steps[self.i][0])
+                self.i += 1
+                return xt
+        n_batches = -(-n // bs)
+        loaders = [[(s[0], s[2]) for s in steps[ep * n_batches:(ep + 1) * n_batches]] for ep in range(epochs)]
+
+        class _Loader:
+            def __init__(self):
+                self.ep = 0
+
+            def __len__(self):
+                return n_batches
+
+            def __iter__(self):
+                it = iter(loaders[self.ep])
+                self.ep += 1
+                return it
+        clf.device = 'cpu'
+        sd0 = {k: v.clone() for k, v in clf.model.state_dict().items()}
+        cfgt = types.SimpleNamespace(learning_rate=1e-3, wandb=False, n_epochs=epochs, n_epochs_no_time=epochs)
+        torch.manual_seed(99)
+        ts = [torch.randint(0, T, (s[0].shape[0],)).to(torch.long) if tc else torch.zeros(s[0].shape[0], dtype=torch.long)
+              for s in steps]
+        torch.manual_seed(99)
+        trained = train_classifier(clf, _Model(), _Loader(), cfgt, save_dir=None, project_fn=None, time_conditioned=tc)
+        sd1 = {k: v.detach().clone() for k, v in trained.model.state_dict().items()}
+        mine, losses = port.train(sd0, [(s[1], t, s[2]) for s, t in zip(steps, ts)], residues=residues)
+        err = max(float((mine[k] - sd1[k]).abs().max()) for k in sd1)
+        assert err < 1e-6, (case, err)
+        print('  train case', case, len(steps), 'steps, restatement vs reference max |dw|', err, 'loss', losses[0], '->', losses[-1])
+        bmax = max(s[0].shape[0] for s in steps)
+        pad = lambda v, fill: torch.stack([torch.cat([q, torch.full((bmax - q.shape[0],) + q.shape[1:], fill, dtype=q.dtype)]) for q in v])
+        out.update({f'{case}_xt': pad([s[1] for s in steps], 0), f'{case}_t': pad(ts, 0), f'{case}_y': pad([s[2] for s in steps], 0.),
+                    f'{case}_nb': torch.tensor([s[0].shape[0] for s in steps]), f'{case}_losses': torch.tensor(losses),
+                    f'{case}_L': L, f'{case}_residues': torch.tensor(residues if residues is not None else []),
+                    f'{case}_tc': int(tc), f'{case}_seed': 17, f'{case}_n_res': n_res})
+        for k in sd1:
+            out[f'{case}_w1_{k}'] = sd1[k]
+    save('train_mlp', **out)
+
+
+GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
