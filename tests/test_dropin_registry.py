@@ -55,3 +55,23 @@ def test_driver_side_imports():
     for attr in ('embedder', 'time_embedder', 'mlp', 'cls_head'):
         assert attr in inspect.getsource(MLPModel.__init__)
     assert issubclass(ProteinPredictor, torch.nn.Module)
+
+
+def test_checkpoint_importer_uses_the_non_executing_loader(tmp_path, monkeypatch):
+    import pytest
+    import torch
+    from sgpo_amd import weights as W
+    p = str(tmp_path / 'best_model.ckpt')
+    torch.save({'state_dict': {'backbone.blocks.0.w': torch.ones(3), 'noise.sigma': torch.zeros(2)}}, p)
+    sd = W.load_lightning_state(p, 'backbone.')
+    assert list(sd) == ['blocks.0.w'] and sd['blocks.0.w'].dtype == torch.float32
+
+    class Hyper:        # a pickled object, as Lightning checkpoints with hyper-parameters carry
+        pass
+    torch.save({'state_dict': {'backbone.w': torch.ones(3)}, 'hyper_parameters': Hyper()}, p)
+    monkeypatch.delenv('SGPO_TRUST_CHECKPOINT', raising=False)
+    with pytest.raises(RuntimeError, match='non-executing loader refused'):
+        W.load_lightning_state(p, 'backbone.')
+    with pytest.raises(KeyError):
+        torch.save({'state_dict': {'other.w': torch.ones(3)}}, p)
+        W.load_lightning_state(p, 'backbone.')
