@@ -57,6 +57,10 @@ def test_driver_side_imports():
     assert issubclass(ProteinPredictor, torch.nn.Module)
 
 
+class _Hyper:        # a pickled object, as Lightning checkpoints with hyper-parameters carry
+    pass
+
+
 def test_checkpoint_importer_uses_the_non_executing_loader(tmp_path, monkeypatch):
     import pytest
     import torch
@@ -65,10 +69,7 @@ def test_checkpoint_importer_uses_the_non_executing_loader(tmp_path, monkeypatch
     torch.save({'state_dict': {'backbone.blocks.0.w': torch.ones(3), 'noise.sigma': torch.zeros(2)}}, p)
     sd = W.load_lightning_state(p, 'backbone.')
     assert list(sd) == ['blocks.0.w'] and sd['blocks.0.w'].dtype == torch.float32
-
-    class Hyper:        # a pickled object, as Lightning checkpoints with hyper-parameters carry
-        pass
-    torch.save({'state_dict': {'backbone.w': torch.ones(3)}, 'hyper_parameters': Hyper()}, p)
+    torch.save({'state_dict': {'backbone.w': torch.ones(3)}, 'hyper_parameters': _Hyper()}, p)
     monkeypatch.delenv('SGPO_TRUST_CHECKPOINT', raising=False)
     with pytest.raises(RuntimeError, match='non-executing loader refused'):
         W.load_lightning_state(p, 'backbone.')
