@@ -88,3 +88,4 @@ int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, con
 // persistent 256x128 kernel (gemm_p.hip); returns SGPO_ERR_UNSUPPORTED when the shape does not fit it
 int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, const bf16_t* zero16, hipStream_t stream);
 int gemm_get_zero16(const bf16_t** out);
+int gemm_cu_count();

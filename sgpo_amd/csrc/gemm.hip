@@ -3,17 +3,21 @@
 #include "prof.h"
 #include <stdlib.h>
 
-#define BM 128
 #define BN 128
 #define BK 64
-#define TILE_BYTES (BM * BK * 2)  // 16 KiB per operand tile
+#define B_TILE_BYTES (BN * BK * 2)  // 16 KiB
 
 typedef const __attribute__((address_space(1))) void* gptr_t;
 typedef __attribute__((address_space(3))) void* lptr_t;
 
-template <int EPI>
+// MTW = 32-row MFMA tiles per wave along M: tile = (64 * MTW) x 128.  MTW = 1 fills the GPU at small M
+// (a few sequences per call); same K order and epilogue arithmetic, so the bits do not depend on the choice.
+template <int EPI, int MTW>
 __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16) {
   extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x (A tile + B tile)
+  constexpr int BM = 64 * MTW, A_TILE_BYTES = BM * BK * 2, STAGE_BYTES = A_TILE_BYTES + B_TILE_BYTES;
+  // LDS ring: 4 slots of 24 KiB (64-row tile) or 3 of 32 KiB; the wave counts its own LDS-DMA operations
+  constexpr int NST = MTW == 1 ? 4 : 3, OPS = 2 * MTW + 4;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -32,19 +36,24 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
   const int n0 = (bid % ntn) * BN;
 
   // ---- per-lane staging coordinates (4 LDS-DMA instructions per operand per wave)
-  const bf16_t* a_src[4];
-  int a_l[4];
+  const bf16_t* a_src[2 * MTW];
+  int a_l[2 * MTW];
   const bf16_t* w_src[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int i = wave * 4 + j;
+  for (int j = 0; j < 2 * MTW; ++j) {
+    const int i = wave * 2 * MTW + j;
     const int row = i * 8 + (lane >> 3);
-    const int pc = lane & 7;
-    const int c = pc ^ ((row >> 1) & 7);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
     int m = m0 + row;
     if (m > p.M - 1) m = p.M - 1;
     a_src[j] = p.A + (size_t)m * p.lda + c * 8;
     a_l[j] = m % p.L;
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int i = wave * 4 + j;
+    const int row = i * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((row >> 1) & 7);
     int n = n0 + row;
     if (n > p.N - 1) n = p.N - 1;
     w_src[j] = p.W + (size_t)n * p.ldw + c * 8;
@@ -55,11 +64,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
     const int seg = kglob / sg.seg_k;
     const int kin = kglob - seg * sg.seg_k;
     const int sh = sg.shift[seg];
-    char* abase = smem + buf * (2 * TILE_BYTES);
-    char* bbase = abase + TILE_BYTES;
+    char* abase = smem + buf * STAGE_BYTES;
+    char* bbase = abase + A_TILE_BYTES;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const int i = wave * 4 + j;
+    for (int j = 0; j < 2 * MTW; ++j) {
+      const int i = wave * 2 * MTW + j;
       const bf16_t* src = a_src[j] + (ptrdiff_t)sh * p.lda + kin;
       const int lp = a_l[j] + sh;
       if (lp < 0 || lp >= p.L) src = zero16;  // zero padding at the sequence ends (conv taps)
@@ -72,9 +81,9 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
     }
   };
 
-  f32x16 acc[2][2];
+  f32x16 acc[MTW][2];
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < MTW; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
@@ -82,48 +91,63 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
 
   // fragment read offsets (bytes inside a tile): row*128 + ((c ^ ((row>>1)&7)) * 16)
   const int lr = lane & 31, lh = lane >> 5;
-  int a_off[2], b_off[2], a_sw[2], b_sw[2];
+  int a_off[MTW], b_off[2], a_sw[MTW], b_sw[2];
+#pragma unroll
+  for (int t = 0; t < MTW; ++t) {
+    const int ra = wr * 32 * MTW + t * 32 + lr;
+    a_off[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t) {
-    const int ra = wr * 64 + t * 32 + lr;
     const int rb = wc * 64 + t * 32 + lr;
-    a_off[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
     b_off[t] = rb * 128; b_sw[t] = (rb >> 1) & 7;
   }
 
   const int nk = p.K / BK;
-  stage(0, 0);
+#pragma unroll
+  for (int s = 0; s < NST - 1; ++s)
+    if (s < nk) stage(s, s);
+  int slot = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (kt + 1 < nk) stage((kt + 1) & 1, kt + 1);
-    const char* abase = smem + (kt & 1) * (2 * TILE_BYTES);
-    const char* bbase = abase + TILE_BYTES;
+    // stage kt has landed once at most `ahead` younger stages (OPS operations each) are outstanding
+    const int ahead = min(NST - 2, nk - 1 - kt);
+    if (ahead >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * OPS) : "memory");
+    else if (ahead == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(OPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();   // every wave's pieces of stage kt are visible; every read of stage kt-1 is done
+    asm volatile("" ::: "memory");
+    if (kt + NST - 1 < nk) {
+      int ps = slot + NST - 1;
+      if (ps >= NST) ps -= NST;
+      stage(ps, kt + NST - 1);
+    }
+    const char* abase = smem + slot * STAGE_BYTES;
+    const char* bbase = abase + A_TILE_BYTES;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int c = kk * 2 + lh;
-      bf16x8 af[2], bfr[2];
+      bf16x8 af[MTW], bfr[2];
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        af[t] = *reinterpret_cast<const bf16x8*>(abase + a_off[t] + ((c ^ a_sw[t]) << 4));
-        bfr[t] = *reinterpret_cast<const bf16x8*>(bbase + b_off[t] + ((c ^ b_sw[t]) << 4));
-      }
+      for (int t = 0; t < MTW; ++t) af[t] = *reinterpret_cast<const bf16x8*>(abase + a_off[t] + ((c ^ a_sw[t]) << 4));
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int t = 0; t < 2; ++t) bfr[t] = *reinterpret_cast<const bf16x8*>(bbase + b_off[t] + ((c ^ b_sw[t]) << 4));
+#pragma unroll
+      for (int a = 0; a < MTW; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
     }
+    if (++slot == NST) slot = 0;
   }
 
   // ---------------------------------------------------------------- epilogue
   // D[row = (r&3) + 8*(r>>2) + 4*lh][col = lr]
   const int ncol0 = n0 + wc * 64;
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wr * 64 + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int m = m0 + wr * 32 * MTW + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
       if (m >= p.M) continue;
       float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
       const int na = ncol0 + lr, nb = ncol0 + 32 + lr;
@@ -177,6 +201,17 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
   }
 }
 
+int gemm_cu_count() {
+  static int n_cu = 0;
+  if (!n_cu) {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    hipDeviceProp_t pr;
+    n_cu = (hipGetDeviceProperties(&pr, dev) == hipSuccess) ? pr.multiProcessorCount : 256;
+  }
+  return n_cu;
+}
+
 static const bf16_t* g_zero16[16] = {nullptr};
 
 int gemm_get_zero16(const bf16_t** out) {
@@ -220,19 +255,26 @@ int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, con
       if (rc != SGPO_ERR_UNSUPPORTED) return rc;
     }
   }
-  const int ntm = (p.M + BM - 1) / BM, ntn = (p.N + BN - 1) / BN;
+  const int ntn = (p.N + BN - 1) / BN;
+  // 64-row tiles while 128-row tiles would leave CUs idle
+  const bool small = ((p.M + 127) / 128) * ntn < gemm_cu_count();
+  const int bm = small ? 64 : 128;
+  const int ntm = (p.M + bm - 1) / bm;
   dim3 grid(ntm * ntn), block(256);
-  const size_t lds = 4 * TILE_BYTES;
+  const size_t lds = (small ? 4 : 3) * ((size_t)bm * BK * 2 + B_TILE_BYTES);
   ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
 #define LAUNCH(E)                                                                                   \
   case E: {                                                                                         \
     static bool attr_set = false;                                                                   \
     if (!attr_set) {                                                                                \
-      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<E>),        \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));    \
+      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<E, 2>),     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 98304));       \
+      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_bf16_kernel<E, 1>),     \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, 98304));       \
       attr_set = true;                                                                              \
     }                                                                                               \
-    hipLaunchKernelGGL(gemm_bf16_kernel<E>, grid, block, lds, stream, p, sg, z);                    \
+    if (small) hipLaunchKernelGGL((gemm_bf16_kernel<E, 1>), grid, block, lds, stream, p, sg, z);    \
+    else hipLaunchKernelGGL((gemm_bf16_kernel<E, 2>), grid, block, lds, stream, p, sg, z);          \
   } break;
   switch (epi) {
     LAUNCH(EPI_BF16)
