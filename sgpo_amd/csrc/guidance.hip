@@ -160,10 +160,23 @@ __global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* _
     __syncthreads();
   }
   const int64_t* xr = x + (size_t)b * L;
-  for (int i = 0; i < d.n_read; ++i) {
-    int tok = (int)xr[d.read_pos[i]];
-    tok = tok < 0 ? 0 : (tok >= d.alphabet ? d.alphabet - 1 : tok);
-    pre += d.T1[((size_t)i * d.alphabet + tok) * MH + j];
+  // eight table rows in flight per lane (one sequence is one wave: a dependent load per residue is pure latency);
+  // the sum keeps its order
+  for (int i0 = 0; i0 < d.n_read; i0 += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int i = i0 + u;
+      v[u] = 0.f;
+      if (i < d.n_read) {
+        int tok = (int)xr[d.read_pos[i]];
+        tok = tok < 0 ? 0 : (tok >= d.alphabet ? d.alphabet - 1 : tok);
+        v[u] = d.T1[((size_t)i * d.alphabet + tok) * MH + j];
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u)
+      if (i0 + u < d.n_read) pre += v[u];
   }
   if (hpre) hpre[(size_t)b * MH + j] = pre;
   if (cnt) {
@@ -251,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restric
                                                        const float* __restrict__ hpre, const int64_t* __restrict__ x,
                                                        float b5, int B, int n_read, int alphabet, int S, int L,
                                                        int mask_index, const int* __restrict__ cnt,
-                                                       const unsigned short* __restrict__ lists,
+                                                       const unsigned short* __restrict__ lists, int spread,
                                                        float* __restrict__ log_ratio) {
   __shared__ float wl[3 * MH * MH];
   __shared__ float bl[4 * MH];
@@ -263,16 +276,21 @@ __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restric
   const int n_waves = gridDim.x * 4;
   const bool compact = cnt != nullptr;
   const int mask_tok = mask_index < 0 ? 0 : (mask_index >= alphabet ? alphabet - 1 : mask_index);
-  // compact: a wave walks whole sequences (their tile counts differ); otherwise tiles are dealt singly
-  const int n_units = compact ? B : B * n_read;
+  // compact: a wave walks whole sequences (their tile counts differ) -- or, for small batches (`spread`), one
+  // tile slot of a sequence, so that a handful of sequences still spreads over the GPU; otherwise tiles are
+  // dealt singly
+  const int per = (compact && !spread) ? 1 : n_read;
+  const int n_units = B * per;
   for (int unit = blockIdx.x * 4 + wave; unit < n_units; unit += n_waves) {
-    const int b = compact ? unit : unit / n_read;
+    const int b = unit / per;
     int nm = 1, nu = 0;
     if (compact) { nm = cnt[2 * b]; nu = cnt[2 * b + 1]; }
     const int n_t = compact ? nm + (nu + 30) / 31 : 1;
     const unsigned short* ml = compact ? lists + (size_t)b * 2 * n_read : nullptr;
     const float* hp = hpre + (size_t)b * MH;
-    for (int j = 0; j < n_t; ++j) {
+    const int j0 = (compact && spread) ? unit % per : 0;
+    const int j1 = (compact && spread) ? (j0 + 1 < n_t ? j0 + 1 : n_t) : n_t;
+    for (int j = j0; j < j1; ++j) {
       // The 192 weight fragments are the same for every tile; hoisted out of this loop they would need
       // 192 VGPRs and spill to scratch.  An opaque (always zero) offset keeps the LDS reads inside.
       int wofs = 0;
@@ -373,7 +391,8 @@ static int guidance_ratio(sgpo_mlp* m, const int64_t* x, float t, int B, int L, 
     hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, st, mlp_dev(m), x, (const float*)nullptr, t, L, hpre,
                        (float*)nullptr, mask_index, compact ? cnt : (int*)nullptr, compact ? lists : (unsigned short*)nullptr);
   }
-  const int n_units = compact ? B : B * m->n_read;
+  const int spread = (compact && B < 1024) ? 1 : 0;   // few sequences: one tile slot per wave instead of one sequence
+  const int n_units = (compact && !spread) ? B : B * m->n_read;
   int blocks = (n_units + 3) / 4;
   if (blocks > 256 * 3) blocks = 256 * 3;  // 3 resident blocks per CU (LDS 49 KiB each), grid-stride the rest
   // b5 is added to both f and fbase and cancels in the ratio.
@@ -384,7 +403,7 @@ static int guidance_ratio(sgpo_mlp* m, const int64_t* x, float t, int B, int L, 
   ProfScope prof_scope(PK_MLP_JUMP, st, compact ? (double)B * m->n_read * per_jump : (double)B * m->n_read * S * per_jump);
   hipLaunchKernelGGL(mlp_jump_kernel, dim3(blocks), dim3(256), 0, st, m->w_perm, m->bias_perm, m->T1, m->read_pos, hpre, x,
                      b5, B, m->n_read, m->alphabet, S, L, mask_index, compact ? cnt : (const int*)nullptr,
-                     compact ? lists : (const unsigned short*)nullptr, log_ratio);
+                     compact ? lists : (const unsigned short*)nullptr, spread, log_ratio);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
