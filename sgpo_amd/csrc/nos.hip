@@ -32,14 +32,14 @@ struct NosArgs {
 };
 
 template <int H, int MODE>
-__global__ __launch_bounds__(256) void nos_row_kernel(NosArgs a) {
+__global__ __launch_bounds__(512) void nos_row_kernel(NosArgs a) {   // 8 waves share one copy of W in LDS
   extern __shared__ float wl[];  // [V][H]
   constexpr int PER = H / 64;
-  for (int i = threadIdx.x; i < a.V * H; i += 256) wl[i] = a.W[i];
+  for (int i = threadIdx.x; i < a.V * H; i += 512) wl[i] = a.W[i];
   __syncthreads();
   const int lane = threadIdx.x & 63;
-  const int wid = blockIdx.x * 4 + (threadIdx.x >> 6);
-  const int n_waves = gridDim.x * 4;
+  const int wid = blockIdx.x * 8 + (threadIdx.x >> 6);
+  const int n_waves = gridDim.x * 8;
   for (int row = wid; row < a.rows; row += n_waves) {
     int b = row / a.L;
     if (b > a.B - 1) b = a.B - 1;
@@ -67,43 +67,44 @@ __global__ __launch_bounds__(256) void nos_row_kernel(NosArgs a) {
       g[i] = a.norm_w[col] * (1.f + sc[col]);
       xn[i] = y[i] * g[i] + sh[col];
     }
-    // logits (every lane ends up with all V values)
-    float z[32];
+    // logits: per-lane partial dot products, then a reduce-scatter over the wave (32 shuffles instead of 6 per
+    // logit): lane l ends up with the total of logit k = (l >> 1) & 31 (both lanes of a pair hold it)
+    float acc[32];
 #pragma unroll
     for (int k = 0; k < 32; ++k) {
+      acc[k] = 0.f;
       if (k < a.V) {
-        float acc = 0.f;
 #pragma unroll
-        for (int i = 0; i < PER; ++i) acc = fmaf(wl[k * H + i * 64 + lane], xn[i], acc);
-        z[k] = wave_sum(acc) + a.bias[k];
-      } else {
-        z[k] = -INFINITY;
+        for (int i = 0; i < PER; ++i) acc[k] = fmaf(wl[k * H + i * 64 + lane], xn[i], acc[k]);
       }
     }
-    if (MODE == NOS_FINAL) {
-      float mine = 0.f;
+    const bool b5 = lane & 32, b4 = lane & 16, b3 = lane & 8, b2 = lane & 4, b1 = lane & 2;
+    float r16[16], r8[8], r4[4], r2[2];
 #pragma unroll
-      for (int k = 0; k < 32; ++k) if (lane == k) mine = z[k];
-      if (lane < a.V) a.logits_out[(size_t)row * a.V + lane] = mine;
+    for (int i = 0; i < 16; ++i) r16[i] = (b5 ? acc[16 + i] : acc[i]) + __shfl_xor(b5 ? acc[i] : acc[16 + i], 32);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r8[i] = (b4 ? r16[8 + i] : r16[i]) + __shfl_xor(b4 ? r16[i] : r16[8 + i], 16);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) r4[i] = (b3 ? r8[4 + i] : r8[i]) + __shfl_xor(b3 ? r8[i] : r8[4 + i], 8);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) r2[i] = (b2 ? r4[2 + i] : r4[i]) + __shfl_xor(b2 ? r4[i] : r4[2 + i], 4);
+    float zl = (b1 ? r2[1] : r2[0]) + __shfl_xor(b1 ? r2[0] : r2[1], 2);
+    zl += __shfl_xor(zl, 1);
+    const int kl = (lane >> 1) & 31;
+    const bool first = (lane & 1) == 0;
+    zl = kl < a.V ? zl + a.bias[kl] : -INFINITY;
+    if (MODE == NOS_FINAL) {
+      if (first && kl < a.V) a.logits_out[(size_t)row * a.V + kl] = zl;
       continue;
     }
     // softmax over the non-mask columns (subs parameterisation: mask logit += -1e6 -> weight 0)
-    float zmax = -INFINITY;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) if (k < a.V && k != a.mask_index) zmax = fmaxf(zmax, z[k]);
-    float p[32];
-    float se = 0.f;
-#pragma unroll
-    for (int k = 0; k < 32; ++k) {
-      p[k] = (k < a.V && k != a.mask_index) ? expf(z[k] - zmax) : 0.f;
-      se += p[k];
-    }
-    const float inv = 1.0f / se;
+    const bool valid = kl < a.V && kl != a.mask_index;
+    const float zmax = wave_max(valid ? zl : -INFINITY);
+    const float e = valid ? expf(zl - zmax) : 0.f;
+    const float inv = 1.0f / wave_sum(first ? e : 0.f);
+    const float pl = e * inv;
     if (MODE == NOS_INIT) {
-      float mine = 0.f;
-#pragma unroll
-      for (int k = 0; k < 32; ++k) if (lane == k) mine = p[k] * inv;
-      if (lane < 32) a.p0[(size_t)row * 32 + lane] = mine;
+      if (first) a.p0[(size_t)row * 32 + kl] = pl;
 #pragma unroll
       for (int i = 0; i < PER; ++i) {
         a.delta[(size_t)row * H + i * 64 + lane] = 0.f;
@@ -118,10 +119,11 @@ __global__ __launch_bounds__(256) void nos_row_kernel(NosArgs a) {
       float dxn[PER];
 #pragma unroll
       for (int i = 0; i < PER; ++i) dxn[i] = 0.f;
+      const float dzl = valid ? a.cscale * (pl - a.p0[(size_t)row * 32 + kl]) : 0.f;
 #pragma unroll
       for (int k = 0; k < 32; ++k) {
         if (k < a.V && k != a.mask_index) {
-          const float dz = a.cscale * (p[k] * inv - a.p0[(size_t)row * 32 + k]);
+          const float dz = __shfl(dzl, 2 * k);
 #pragma unroll
           for (int i = 0; i < PER; ++i) dxn[i] = fmaf(wl[k * H + i * 64 + lane], dz, dxn[i]);
         }
@@ -151,7 +153,7 @@ __global__ __launch_bounds__(256) void nos_row_kernel(NosArgs a) {
 template <int H>
 static int launch_nos(int mode, const NosArgs& a, hipStream_t st) {
   const size_t lds = (size_t)a.V * H * sizeof(float);
-  int blocks = (a.rows + 3) / 4;
+  int blocks = (a.rows + 7) / 8;
   if (blocks > 512) blocks = 512;
 #define L_(M)                                                                                         \
   case M: {                                                                                           \
@@ -161,7 +163,7 @@ static int launch_nos(int mode, const NosArgs& a, hipStream_t st) {
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));      \
       set = true;                                                                                     \
     }                                                                                                 \
-    hipLaunchKernelGGL((nos_row_kernel<H, M>), dim3(blocks), dim3(256), lds, st, a);                  \
+    hipLaunchKernelGGL((nos_row_kernel<H, M>), dim3(blocks), dim3(512), lds, st, a);                  \
   } break;
   switch (mode) { L_(NOS_INIT) L_(NOS_STEP) L_(NOS_FINAL) }
 #undef L_
