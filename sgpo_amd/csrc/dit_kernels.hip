@@ -185,8 +185,11 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
 // qkv: [M][3*Hd] bf16 (q | k | v sections, heads contiguous inside a section), RoPE already applied.
 #define ATT_D 64
 
-__global__ __launch_bounds__(256, 5) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
-                                                        int L, int Lp, int n_heads, float scale_log2e) {
+// NW waves per workgroup: 4 for short sequences (5 workgroups per CU), 8 once the K/V images leave room for a
+// single workgroup per CU (L > 160: twice the waves in flight behind the same LDS bytes)
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+                                                                         int L, int Lp, int n_heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hid = n_heads * ATT_D;
   const int ld = 3 * hid;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(256, 5) void attention_kernel(const bf16_t* __restr
   const bf16_t* base = qkv + (size_t)b * L * ld + h * ATT_D;
 
   // ---- stage K (swizzled rows) and V^T; rows >= L are zero
-  for (int idx = tid; idx < Lp * 8; idx += 256) {
+  for (int idx = tid; idx < Lp * 8; idx += 64 * NW) {
     const int row = idx >> 3, c = idx & 7;
     uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
     if (row < L) {
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(256, 5) void attention_kernel(const bf16_t* __restr
   const int v_off1 = (lh * 4 + tq) * 128 + (((4 + dblk * 2 + (tp >> 1)) ^ (tq << 1)) << 4) + (tp & 1) * 8;    // d in [32, 64)
 
   const int n_tiles = Lp / 32;
-  for (int qt = wave; qt < n_tiles; qt += 4) {
+  for (int qt = wave; qt < n_tiles; qt += NW) {
     // Q fragments: B operand, lane holds Q[query = qt*32+lr][d = kk*16 + 8*lh + j]
     int qrow = qt * 32 + lr;
     if (qrow > L - 1) qrow = L - 1;
@@ -321,13 +324,18 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
   SGPO_REQUIRE(lds <= 160 * 1024, "attention: sequence length %d exceeds the LDS-resident limit", L);
   static size_t attr_lds = 0;
   if (lds > attr_lds) {
-    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel),
+    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<4>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
   ProfScope prof_scope(PK_ATTENTION, stream, 4.0 * B * n_heads * (double)L * L * head_dim);
-  hipLaunchKernelGGL(attention_kernel, dim3(B * n_heads), dim3(256), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
+  if (lds > 40 * 1024)
+    hipLaunchKernelGGL(attention_kernel<8>, dim3(B * n_heads), dim3(512), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
+  else
+    hipLaunchKernelGGL(attention_kernel<4>, dim3(B * n_heads), dim3(256), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }

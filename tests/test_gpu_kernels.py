@@ -81,6 +81,31 @@ def test_dit_forward(rt, name):
     assert err2 < 1e-2, f'x_emb path: {err2:.3e}'
 
 
+@pytest.mark.parametrize('dims,B,L', [(dict(hidden=128, cond_dim=32, n_blocks=2, n_heads=2), 3, 389),
+                                      (dict(hidden=512, cond_dim=128, n_blocks=2, n_heads=8), 2, 389),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 161)])
+def test_dit_forward_long_sequences(rt, dims, B, L):
+    """TrpB length (389) and the first length past the 4-wave attention kernel (K/V images > 40 KB switch to 8 waves
+    per workgroup): device logits against the CPU restatement rounding to bf16 where autocast does."""
+    from oracle import dit as odit
+    from sgpo_amd import weights as W
+    sd = W.dit_synthetic_state(seed=9, vocab=31, **dims)
+    net = rt.DitDenoiser(sd)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, 31, (B, L), generator=g)
+    sigma = torch.rand(B, generator=g) * 3
+    logits = net.forward(x.cuda(), sigma.cuda()).cpu()
+    ref16 = odit.dit_forward(sd, x, sigma, emulate_bf16=True)
+    ref32 = odit.dit_forward(sd, x, sigma)
+    scale = ref32.abs().max()
+    err, err_emu = (logits - ref32).abs().max() / scale, (ref16 - ref32).abs().max() / scale
+    print(f'L={L} hidden={dims["hidden"]}: dev-vs-fp32 {err:.3e}  bf16emu-vs-fp32 {err_emu:.3e}')
+    assert err < 2.0 * err_emu + 2e-3 and (logits - ref16).abs().max() / scale < 1.5e-2
+    # a sequence's logits do not depend on its neighbours in the batch
+    one = net.forward(x[1:2].cuda(), sigma[1:2].cuda()).cpu()
+    assert torch.equal(one[0], logits[1])
+
+
 @pytest.mark.parametrize('B', [12, 36])     # M = 1428: 256x128 tiles only; M = 4284: 256x256 tiles with a ragged last tile
 def test_dit_forward_large_batch_uses_persistent_gemm(rt, B):
     """M = B*L >= 1024 routes every GEMM (all epilogues: RoPE, GELU, gate+residual, vocab head) through
