@@ -563,7 +563,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     __builtin_amdgcn_s_barrier();
     asm volatile("" ::: "memory");
   }
-  if (grp == 1) __builtin_amdgcn_s_barrier();
+  if (grp == 1 && !ABL(8)) __builtin_amdgcn_s_barrier();
   STAMP_DECL
   int slot = 0;   // ring slot of step s
   int s = 0;      // position in the flattened (tile, k-step) stream
@@ -633,7 +633,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       STAMP_PUT(1, st_a);
       STAMP(2);
-      __builtin_amdgcn_s_barrier();
+      if (!ABL(8)) __builtin_amdgcn_s_barrier();
       STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -665,7 +665,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         __builtin_amdgcn_sched_barrier(0);
         STAMP(5);
       }
-      __builtin_amdgcn_s_barrier();
+      if (!ABL(8)) __builtin_amdgcn_s_barrier();
       STAMP(6);
       asm volatile("" ::: "memory");
     }
@@ -675,7 +675,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
    for (int kt = 0; kt < nk - 1; ++kt) step(kt, std::false_type{});
    step(nk - 1, std::true_type{});
   }
-  if (grp == 0) __builtin_amdgcn_s_barrier();
+  if (grp == 0 && !ABL(8)) __builtin_amdgcn_s_barrier();
   if (!ABL(4) && !(EARLY1 && grp == 1)) {
     int pm0, pn0;
     tile_origin(n_my - 1, pm0, pn0);
