@@ -62,6 +62,20 @@ __device__ __forceinline__ float epi_gelu_tanh(float x) {
   const float e = __builtin_amdgcn_exp2f(rn_mul(x, t));
   return rn_mul(x, __builtin_amdgcn_rcpf(1.0f + e));
 }
+// two elements at a time: the multiplies and the fma map to v_pk_mul_f32 / v_pk_fma_f32 (same IEEE results as the
+// scalar form above, half the VALU issue slots); exp2 and rcp stay one lane-instruction per element
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
+__device__ __forceinline__ f32x2_t epi_gelu_tanh2(f32x2_t x) {
+#pragma clang fp contract(off)
+  const f32x2_t k1 = {-0.10294324f, -0.10294324f}, k0 = {-2.30220819f, -2.30220819f};
+  const f32x2_t xx = x * x;
+  const f32x2_t t = __builtin_elementwise_fma(k1, xx, k0);
+  const f32x2_t a = x * t;
+  f32x2_t r;
+  r.x = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a.x));
+  r.y = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(a.y));
+  return x * r;
+}
 __device__ __forceinline__ float epi_gelu_erf(float x) {
   return rn_mul(rn_mul(0.5f, x), 1.0f + erff(rn_mul(x, 0.7071067811865476f)));
 }

@@ -478,8 +478,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
             float v[4] = {acc[nt][mt][4 * g + 0] + b4.x, acc[nt][mt][4 * g + 1] + b4.y,
                           acc[nt][mt][4 * g + 2] + b4.z, acc[nt][mt][4 * g + 3] + b4.w};
             if constexpr (EPI == EPI_BIAS_GELU) {
-#pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = epi_gelu_tanh(v[q]);
+              const f32x2_t g0 = epi_gelu_tanh2(f32x2_t{v[0], v[1]}), g1 = epi_gelu_tanh2(f32x2_t{v[2], v[3]});
+              v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
             }
             if constexpr (EPI == EPI_BIAS_GELU_ERF) {
 #pragma unroll
