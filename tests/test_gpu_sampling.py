@@ -119,6 +119,45 @@ def test_cg_inference_end_to_end_and_drop_in_api(env):
     assert abs(f_d - f_o) < 0.15 * max(1.0, abs(f_o)), (f_d, f_o)
 
 
+def test_free_run_statistics_4096_samples(env):
+    """SURVEY.md section 4, statistical level: 4096 free-running device samples against 1024 free-running oracle
+    samples (4 independent batches of 256, own noise) -- per-position marginals (total variation), per-position
+    Shannon entropy (diversity) and value-function mean."""
+    from oracle import cls_guidance as ocg
+    from oracle import mlp as omlp
+    g = load_golden('cg_small_guided')
+    T, temp = int(g['T']), float(g['temp'])
+    Lq = g['x'].shape[1]
+    full_seq = bytes(g['full_seq'].numpy().tolist()).decode()
+    net, pred, algo, sd, msd = _build(g, T, Lq, full_seq, temp, int(g['mlp_seed']))
+    net.reseed(777)
+    x = algo.inference(num_samples=4096).cpu()
+    gen = torch.Generator().manual_seed(11)
+    xo = []
+    for _ in range(4):
+        es = torch.empty(T - 1, 256, Lq, 31).exponential_(1, generator=gen)
+        xo.append(ocg.inference_mdlm(sd, 256, Lq, T, 28, es, predictor=omlp.Predictor(msd), temperature=temp))
+    xo = torch.cat(xo)
+    pd_ = torch.nn.functional.one_hot(x, 31).float().mean(0)
+    po = torch.nn.functional.one_hot(xo, 31).float().mean(0)
+    tv = 0.5 * (pd_ - po).abs().sum(-1)
+    # sampling noise alone: E[TV] of two empirical 31-way distributions with 4096 and 1024 draws is ~0.05-0.07
+    assert float(tv.mean()) < 0.10 and float(tv.max()) < 0.20, (float(tv.mean()), float(tv.max()))
+    ent = lambda p: -(p * torch.log(p.clamp_min(1e-12))).sum(-1)
+    hd, ho = ent(pd_), ent(po)
+    # the plug-in entropy of 1024 draws is biased low by ~(k-1)/(2n) ~ 0.01 nats; allow 0.06 on the mean
+    assert abs(float(hd.mean() - ho.mean())) < 0.06, (float(hd.mean()), float(ho.mean()))
+    with torch.no_grad():
+        fd = pred.log_likelihood(x.cuda()).cpu()
+        fo = omlp.Predictor(msd).log_likelihood(xo)
+    se = float((fd.var() / 4096 + fo.var() / 1024).sqrt())
+    assert abs(float(fd.mean() - fo.mean())) < 4 * se + 1e-3, (float(fd.mean()), float(fo.mean()), se)
+    # unique fraction (the diversity number update_data sees) agrees as well
+    ud = len({tuple(r.tolist()) for r in x[:1024]}) / 1024
+    uo = len({tuple(r.tolist()) for r in xo}) / 1024
+    assert abs(ud - uo) < 0.05, (ud, uo)
+
+
 def test_get_guided_rates_signature(env):
     """The reference-signature entry point (models/mdlm.py:340-413) on the fused jump kernel."""
     g = load_golden('cg_small_guided')
