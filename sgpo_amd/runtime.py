@@ -505,6 +505,8 @@ def categorical_sample(probs, noise_src=None, noise=None, noise_mode=None):
         noise_mode = L.NOISE_PHILOX
     seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
     out = torch.empty(probs.shape[:-1], dtype=torch.int64, device=probs.device)
+    # the kernel counts rows of K probabilities; the noise source counts sequences (leading dimension)
+    row_off = row_off * (rows // probs.shape[0]) if probs.dim() > 1 and probs.shape[0] > 0 else row_off
     L.check(lib.sgpo_categorical_sample(L.ptr(probs), rows, K, noise_mode, L.ptr(noise), seed, off, row_off,
                                         L.ptr(out), L.stream_ptr()), 'sgpo_categorical_sample')
     return out
