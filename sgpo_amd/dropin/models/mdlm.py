@@ -102,6 +102,7 @@ class MDLM(GenerativeModel):
         self.parameterization = cfg_get(config, 'parameterization', 'subs')
         self.time_conditioning = bool(cfg_get(config, 'time_conditioning', False))
         self.t_next_mode = t_next_mode
+        self.global_batch = None        # set by a sharded caller: the unsharded batch size (NOS batchmean KL)
         self.noise_source = rt.NoiseSource(seed=torch.initial_seed())
         self.injected_noise = deque()   # parity runs: tensors consumed by successive sampling calls
         self._nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
@@ -253,7 +254,10 @@ class MDLM(GenerativeModel):
 
     def _nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t):
         from .nos_step import nos_denoise
-        return nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t)
+        # KLDivLoss(reduction='batchmean') (models/mdlm.py:254,297) divides by the batch of the CALL: when a batch is
+        # sharded over ranks the caller sets `net.global_batch` to the unsharded size
+        return nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t,
+                           kl_batch=getattr(self, 'global_batch', None))
 
 
 _slot_cache = {}

@@ -277,3 +277,40 @@ def test_full_size_properties_config3(env):
     assert torch.equal(whole[:, frozen], parent[frozen].expand(B, -1))
     assert int(whole.min()) >= 0 and int(whole.max()) < 26
     assert bool((whole[:, algo.residues] != parent[algo.residues]).any())
+
+
+def test_full_size_properties_config4(env):
+    """BASELINE config 4 shapes (200 sequences x 389 residues, DiT h512 x 8 blocks, 5 NOS steps of size 0.5) on a short
+    horizon: determinism and ragged 3-way shard invariance -- the batchmean KL of the NOS objective takes the
+    unsharded batch through `net.global_batch` -- and the projection onto the 15 designable residues."""
+    from models.mdlm import MDLM
+    from problem.protein_nos import NOSHead
+    from sampling.NOS import NOS
+    from sgpo_amd import weights as W
+    from sgpo_amd.dist import shard_bounds
+    res = [117, 118, 119, 162, 166, 182, 183, 184, 185, 186, 227, 228, 230, 231, 301]
+    Lq, B = 389, 200
+    g = torch.Generator().manual_seed(0)
+    full = ''.join(ALPHABET[int(t)] for t in torch.randint(0, 20, (Lq,), generator=g))
+    cfg = dict(diffusion='absorbing_state', parameterization='subs', time_conditioning=False,
+               model=dict(hidden_size=512, cond_dim=128, n_blocks=8, n_heads=8, length=1024))
+    net = MDLM('synthetic', cfg, None, num_steps=7, seq_len=Lq, device='cuda:0', state_dict=W.dit_synthetic_state(seed=0))
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq=full, residues=res)
+    torch.manual_seed(1)
+    head = NOSHead(512).cuda().eval()
+    algo = NOS(net, dc, forward_op=head, num_nos_steps=5, nos_step_size=0.5, nos_stability_coef=0.1, device='cuda:0')
+    net.reseed(3, row_offset=0)
+    whole = algo.inference(num_samples=B, verbose=False)
+    net.reseed(3, row_offset=0)
+    assert torch.equal(whole, algo.inference(num_samples=B, verbose=False))
+    net.global_batch = B
+    parts = []
+    for r in range(3):
+        lo, hi = shard_bounds(B, r, 3)
+        net.reseed(3, row_offset=lo)
+        parts.append(algo.inference(num_samples=hi - lo, verbose=False))
+    net.global_batch = None
+    assert torch.equal(torch.cat(parts), whole)
+    frozen = [l for l in range(Lq) if l not in algo.residues]
+    parent = torch.tensor([ALPHABET.index(c) for c in full], device=whole.device)
+    assert torch.equal(whole[:, frozen], parent[frozen].expand(B, -1))
