@@ -112,8 +112,13 @@ def check(rc, what=''):
 
 
 def ptr(t):
-    """Device/host address of a torch tensor (None -> NULL)."""
-    return None if t is None else C.c_void_p(t.data_ptr())
+    """Device address of a torch tensor (None -> NULL).  Every tensor argument of the library is device memory: a
+    host tensor here would hand a kernel a host pointer (a GPU memory fault), so it is refused."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SgpoError(f'host tensor {tuple(t.shape)} {t.dtype} passed where the library expects device memory')
+    return C.c_void_p(t.data_ptr())
 
 
 def stream_ptr():

@@ -442,8 +442,8 @@ def reverse_step_mdlm(logits, x, mt, ms, mask_index, step_mode, noise_src=None, 
     x = x.contiguous()
     logits = logits.contiguous()
     if noise is not None:
-        noise = noise.contiguous()
         assert noise.dtype == torch.float32
+        noise = noise.to(logits.device).contiguous()    # a host pointer handed to a kernel is a GPU fault
         if noise_mode is None:
             noise_mode = L.NOISE_EXPONENTIAL if step_mode == L.STEP_SOFT_CG else L.NOISE_UNIFORM
     elif noise_mode is None:
@@ -467,7 +467,7 @@ def reverse_step_udlm(logits, x, mt, ms, step_mode, noise_src=None, noise=None, 
     logits = logits.contiguous()
     noise_mode = L.NOISE_PHILOX if noise is None else L.NOISE_UNIFORM
     if noise is not None:
-        noise = noise.contiguous()
+        noise = noise.to(logits.device, torch.float32).contiguous()
     seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
     probs = torch.empty_like(logits) if (want_probs or step_mode == L.STEP_SOFT) else None
     x_out = torch.empty_like(x) if step_mode != L.STEP_SOFT else None
@@ -485,7 +485,7 @@ def q_sample_mdlm(x, move_chance, mask_index, noise_src=None, noise=None):
     assert move_chance.numel() == B
     noise_mode = L.NOISE_PHILOX if noise is None else L.NOISE_UNIFORM
     if noise is not None:
-        noise = noise.contiguous()
+        noise = noise.to(x.device, torch.float32).contiguous()
     seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
     out = torch.empty_like(x)
     L.check(lib.sgpo_q_sample_mdlm(L.ptr(x), L.ptr(move_chance), B, Lq, mask_index, noise_mode, L.ptr(noise), seed, off,
@@ -498,8 +498,10 @@ def categorical_sample(probs, noise_src=None, noise=None, noise_mode=None):
     K = probs.shape[-1]
     rows = probs.numel() // K
     probs = probs.to(torch.float32).contiguous()
+    if not probs.is_cuda:
+        raise L.SgpoError('categorical_sample: probabilities must live on the GPU')
     if noise is not None:
-        noise = noise.to(torch.float32).contiguous()
+        noise = noise.to(probs.device, torch.float32).contiguous()
         noise_mode = L.NOISE_EXPONENTIAL if noise_mode is None else noise_mode
     else:
         noise_mode = L.NOISE_PHILOX
