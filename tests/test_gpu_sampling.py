@@ -314,3 +314,42 @@ def test_full_size_properties_config4(env):
     frozen = [l for l in range(Lq) if l not in algo.residues]
     parent = torch.tensor([ALPHABET.index(c) for c in full], device=whole.device)
     assert torch.equal(whole[:, frozen], parent[frozen].expand(B, -1))
+
+
+def test_model_sampler_matrix_remaining_combinations(env):
+    """The README matrix beyond the benchmarked pairs: UDLM (uniform diffusion, d3pm parameterisation, time-conditioned)
+    under the classifier-guided sampler (generic step: no fused kernel for it), and DAPS on an MDLM net.  No oracle trajectory exists for these pairs; each runs end to end and keeps the invariants of the
+    path: determinism under a seed, legal tokens, frozen positions equal to the parent."""
+    from models.mdlm import MDLM
+    from problem.protein import ProteinPredictor
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    from sampling.daps import DAPS
+    from sgpo_amd import weights as W
+    dims = dict(hidden=128, cond_dim=32, n_blocks=2, n_heads=2)
+    sd = W.dit_synthetic_state(seed=4, vocab=31, **dims)
+    Lq, res1 = 30, [3, 4, 5, 10, 11, 20]
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq='M' * Lq, residues=res1)
+    pred = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+    pred.model.load_state_dict(W.mlp_synthetic_state(seed=2, n_residues=len(res1)))
+    pred.eval()
+    frozen = [l for l in range(Lq) if l not in [r - 1 for r in res1]]
+    model = dict(hidden_size=128, cond_dim=32, n_blocks=2, n_heads=2, length=64)
+
+    def check(algo, net, n=12, **kw):
+        net.reseed(31)
+        a = algo.inference(num_samples=n, verbose=False, **kw)
+        net.reseed(31)
+        b = algo.inference(num_samples=n, verbose=False, **kw)
+        assert torch.equal(a, b) and a.shape == (n, Lq) and a.dtype == torch.int64
+        assert int(a.min()) >= 0 and int(a.max()) < 31
+        assert bool((a[:, frozen] == ALPHABET.index('M')).all())
+        return a
+
+    udlm = MDLM('synthetic', dict(diffusion='uniform', parameterization='d3pm', time_conditioning=True, model=model), None,
+                num_steps=16, seq_len=Lq, device='cuda:0', state_dict=sd)
+    check(Classifier_Guidance_Inpaint(udlm, dc, forward_op=pred, temperature=0.5, device='cuda:0'), udlm)
+    mdlm = MDLM('synthetic', dict(diffusion='absorbing_state', parameterization='subs', time_conditioning=False, model=model),
+                None, num_steps=16, seq_len=Lq, device='cuda:0', state_dict=sd)
+    x = check(DAPS(mdlm, forward_op=pred, num_steps=3, ode_steps=4, mh_steps=100, alpha=4., beta=1., data_config=dc,
+                   device='cuda:0'), mdlm)
+    assert bool((x[:, [r - 1 for r in res1]] != ALPHABET.index('M')).any())
