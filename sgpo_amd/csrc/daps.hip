@@ -120,6 +120,7 @@ __global__ __launch_bounds__(256, 2) void daps_mh_kernel(MhArgs a) {
       u = (float)(p.z >> 8) * (1.0f / 16777216.0f);
     } else {
       r = a.r_idx[(size_t)s * a.N + seq];
+      r = r < 0 ? 0 : (r >= a.n_res ? a.n_res - 1 : r);   // injected indices address LDS and global tables
       v = a.r_val[(size_t)s * a.N + seq];
       u = a.r_u[(size_t)s * a.N + seq];
     }
