@@ -222,9 +222,18 @@ static MlpDev mlp_dev(const sgpo_mlp* m) {
   return d;
 }
 
+// every read position must lie inside a row of length L (checked on the host copy; also for negative entries)
+static int check_read_pos(const sgpo_mlp* m, int L, const char* who) {
+  for (int i = 0; i < m->n_read; ++i)
+    SGPO_REQUIRE(m->read_pos_host[i] >= 0 && m->read_pos_host[i] < L, "%s: value function reads position %d of a length-%d row", who,
+                 m->read_pos_host[i], L);
+  return SGPO_OK;
+}
+
 extern "C" int sgpo_mlp_forward(sgpo_mlp* m, const int64_t* x, const float* t, int B, int L, float* out, void* stream) {
   SGPO_REQUIRE(m && x && out, "mlp_forward: null argument");
   SGPO_REQUIRE(B > 0 && L > 0, "mlp_forward: B=%d L=%d", B, L);
+  if (int rc = check_read_pos(m, L, "mlp_forward")) return rc;
   hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, mlp_dev(m), x, t, 0.f, L,
                      (float*)nullptr, out, -1, (int*)nullptr, (unsigned short*)nullptr);
   SGPO_CHECK_HIP(hipGetLastError());
@@ -375,6 +384,7 @@ static int guidance_ratio(sgpo_mlp* m, const int64_t* x, float t, int B, int L, 
   SGPO_REQUIRE(B > 0 && L > 0 && S > 0 && S <= 32 && S <= m->alphabet, "guidance_ratio_mlp: B=%d L=%d S=%d (S <= min(32, alphabet))", B, L, S);
   SGPO_REQUIRE(mask_index < S, "guidance_ratio_mlp: mask_index %d outside the %d target states", mask_index, S);
   SGPO_REQUIRE(m->n_read < 65536, "guidance_ratio_mlp: n_read %d", m->n_read);
+  if (int rc = check_read_pos(m, L, "guidance_ratio_mlp")) return rc;
   if (workspace_bytes < sgpo_mlp_workspace_bytes(m, B)) {
     sgpo_set_error("guidance_ratio_mlp: workspace %zu < required %zu bytes", workspace_bytes, sgpo_mlp_workspace_bytes(m, B));
     return SGPO_ERR_WORKSPACE;

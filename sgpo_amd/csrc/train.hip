@@ -357,6 +357,7 @@ __global__ void tr_adam(TrDev d, float lr_over_bc1, float bc2_sqrt, float beta1,
 struct sgpo_mlp_trainer {
   TrDev d;
   int* read_pos_dev;
+  int max_read_pos;
   long long step;
   size_t mid_lds;
 };
@@ -408,6 +409,11 @@ extern "C" int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_
   HIPF(hipMalloc((void**)&d.part_e, (size_t)d.E * n_read * 32 * H * 4));
   HIPF(hipMalloc((void**)&t->read_pos_dev, (size_t)n_read * sizeof(int)));
   HIPF(hipMemcpy(t->read_pos_dev, read_pos, (size_t)n_read * sizeof(int), hipMemcpyHostToDevice));
+  t->max_read_pos = 0;
+  for (int i = 0; i < n_read; ++i) {
+    if (read_pos[i] < 0) { sgpo_set_error("mlp_trainer_create: negative read position"); sgpo_mlp_trainer_destroy(t); return SGPO_ERR_ARG; }
+    if (read_pos[i] > t->max_read_pos) t->max_read_pos = read_pos[i];
+  }
   d.read_pos = t->read_pos_dev;
   HIPF(hipMemcpy(d.params, blobs, EP * 4, hipMemcpyDeviceToDevice));
   HIPF(hipMemset(d.grads, 0, EP * 4));
@@ -426,6 +432,7 @@ extern "C" int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, cons
   SGPO_REQUIRE(t && x && y && loss_out, "mlp_trainer_step: null argument");
   SGPO_REQUIRE(B > 0 && B <= TB, "mlp_trainer_step: batch %d outside 1..%d", B, TB);
   SGPO_REQUIRE(!t->d.time_cond || tt, "mlp_trainer_step: a time-conditioned model needs t");
+  SGPO_REQUIRE(t->max_read_pos < L, "mlp_trainer_step: value function reads position %d of a length-%d row", t->max_read_pos, L);
   hipStream_t s = (hipStream_t)stream;
   const TrDev& d = t->d;
   hipLaunchKernelGGL(tr_fwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);

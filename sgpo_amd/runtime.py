@@ -407,8 +407,11 @@ def landscape_lookup(table, tokens, residues, n_std=20):
     lib = L.load()
     tokens = tokens.to(dev, torch.int64).contiguous()
     table = table.to(dev, torch.float32).contiguous()
-    res = torch.as_tensor(residues, dtype=torch.int32).to(dev).contiguous()
+    res_host = [int(r) for r in residues]
     N, Ls = tokens.shape
+    if min(res_host) < 0 or max(res_host) >= Ls:
+        raise L.SgpoError(f'landscape_lookup: residue positions {res_host} outside a length-{Ls} row')
+    res = torch.tensor(res_host, dtype=torch.int32).to(dev).contiguous()
     out = torch.empty(N, dtype=torch.float32, device=dev)
     bad = torch.zeros(1, dtype=torch.int32, device=dev)
     L.check(lib.sgpo_landscape_lookup(L.ptr(table), table.numel(), L.ptr(tokens), N, Ls, L.ptr(res), res.numel(), n_std,
