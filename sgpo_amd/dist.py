@@ -73,6 +73,12 @@ def sharded_inference(algo, num_samples, seed, rank=None, world=None, score_fn=N
         rank = dist.get_rank() if dist.is_initialized() else 0
     lo, hi = shard_bounds(num_samples, rank, world)
     algo.net.reseed(seed=seed, row_offset=lo)
-    x = algo.inference(num_samples=hi - lo, **kw)
+    if hasattr(algo.net, 'global_batch'):
+        algo.net.global_batch = num_samples          # NOS: KLDivLoss(batchmean) divides by the unsharded batch
+    try:
+        x = algo.inference(num_samples=hi - lo, **kw)
+    finally:
+        if hasattr(algo.net, 'global_batch'):
+            algo.net.global_batch = None
     s = score_fn(x) if score_fn is not None else None
     return gather_samples(x, s)
