@@ -22,8 +22,43 @@ TRPB_RES = [117, 118, 119, 162, 166, 182, 183, 184, 185, 186, 227, 228, 230, 231
 L_TRPB, NUM_STEPS, ODE_STEPS, MH_STEPS = 389, 50, 20, 1000
 
 
+def cpu_baseline(sd, msd, n_seq=2):
+    """CPU restatement (oracle/, the reference's formulation) on a bounded sample: 2 ByteNet forwards + posteriors and
+    one 1000-proposal Metropolis-Hastings chain for n_seq sequences, scaled to the 50 x (19 + 1) calls of a run."""
+    from oracle import bytenet as obn
+    from oracle import d3pm as od3pm
+    from oracle import daps as odaps
+    from oracle import mlp as omlp
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    S = 26
+    g = torch.Generator().manual_seed(3)
+    x = torch.randint(0, S, (n_seq, L_TRPB), generator=g)
+    Q_bar, Q = od3pm.q_random_schedule(S, 500)
+    sigma = od3pm.sigma_from_qbar(Q_bar, S)
+    t0 = time.perf_counter()
+    for t, tn in ((400, 380), (380, 360)):
+        e = torch.empty(n_seq * L_TRPB, S, dtype=torch.float64).exponential_(1, generator=g)
+        logits = obn.bytenet_forward(sd, x, torch.tensor([t] * n_seq))
+        x = od3pm.p_sample(logits, x, t, tn, Q, Q_bar, sigma, S, e=e)
+    t_fwd = (time.perf_counter() - t0) / 2
+    pred = omlp.Predictor(msd, TRPB_RES)
+    r_idx = torch.randint(0, len(TRPB_RES), (MH_STEPS, n_seq), generator=g)
+    r_val = torch.randint(0, S, (MH_STEPS, n_seq), generator=g)
+    r_u = torch.rand(MH_STEPS, n_seq, generator=g)
+    t0 = time.perf_counter()
+    odaps.metropolis_hasting(x, pred.log_likelihood, sigma[300], MH_STEPS, 128.0, 1000, [r - 1 for r in TRPB_RES], S, L_TRPB,
+                             r_idx, r_val, r_u)
+    t_mh = time.perf_counter() - t0
+    per_run = NUM_STEPS * ((ODE_STEPS - 1) * t_fwd + t_mh)
+    return dict(value=n_seq / per_run, unit='sequences/s', cores=cores, kind='port',
+                sample='%d sequences: 2 denoiser forwards + posteriors (%.1f s each) and one 1000-proposal MH chain (%.1f s), '
+                       'torch-CPU fp32 oracle, scaled to 50 x (19 forwards + 1 chain)' % (n_seq, t_fwd, t_mh))
+
+
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--batch', type=int, default=2048)
     ap.add_argument('--anneal', type=int, default=2, help='annealing steps to time (of 50)')
     a = ap.parse_args()
@@ -37,10 +72,12 @@ def main():
     dev = 'cuda:0'
     g = torch.Generator().manual_seed(0)
     full = ''.join(ALPHABET[int(t)] for t in torch.randint(0, 20, (L_TRPB,), generator=g))
-    net = D3PM('synthetic', L_TRPB, device=dev, state_dict=W.bytenet_synthetic_state(seed=0))
+    bn_sd = W.bytenet_synthetic_state(seed=0)
+    net = D3PM('synthetic', L_TRPB, device=dev, state_dict=bn_sd)
     dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=L_TRPB, full_seq=full, residues=TRPB_RES)
     pred = ProteinPredictor(dc, dict(hidden_dim=64), device=dev)
-    pred.model.load_state_dict(W.mlp_synthetic_state(seed=1, n_residues=len(TRPB_RES)))
+    msd = W.mlp_synthetic_state(seed=1, n_residues=len(TRPB_RES))
+    pred.model.load_state_dict(msd)
     pred.eval()
     lib = L.load()
 
@@ -79,7 +116,8 @@ def main():
                                '%d sequences per GPU; %d of 50 annealing steps timed (each: 19 denoiser forwards + posterior, '
                                '1000 MH proposals, q_sample), value scaled to 50' % (a.batch, a.anneal)},
         'denoiser_gemm_tflops': round(gf / (gt * 1e-3) / 1e12, 1) if gt else None,
-        'gpu_busy_frac': round(tot * 1e-3 / dt, 4), 'kernels': kernels, 'checksum': int(x.sum())}))
+        'gpu_busy_frac': round(tot * 1e-3 / dt, 4), 'cpu_baseline': None if a.no_cpu_baseline else cpu_baseline(bn_sd, msd),
+        'kernels': kernels, 'checksum': int(x.sum())}))
 
 
 if __name__ == '__main__':
