@@ -209,6 +209,16 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(con
   char* v_lds = smem + Lp * 128;   // Lp * 128 B, chunk c of row r at c ^ ((r & 3) << 1)
   const bf16_t* base = qkv + (size_t)b * L * ld + h * ATT_D;
 
+  // Q fragments of this wave's first query tile are requested before the K/V staging so that both latencies overlap.
+  // B operand: lane holds Q[query = qt*32+lr][d = kk*16 + 8*lh + j]
+  bf16x8 qf[4];
+  {
+    int qrow = wave * 32 + lr;
+    if (qrow > L - 1) qrow = L - 1;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+      qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
+  }
   // ---- stage K (swizzled rows) and V^T; rows >= L are zero
   for (int idx = tid; idx < Lp * 8; idx += 64 * NW) {
     const int row = idx >> 3, c = idx & 7;
@@ -229,13 +239,13 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(con
 
   const int n_tiles = Lp / 32;
   for (int qt = wave; qt < n_tiles; qt += NW) {
-    // Q fragments: B operand, lane holds Q[query = qt*32+lr][d = kk*16 + 8*lh + j]
-    int qrow = qt * 32 + lr;
-    if (qrow > L - 1) qrow = L - 1;
-    bf16x8 qf[4];
+    if (qt != wave) {
+      int qrow = qt * 32 + lr;
+      if (qrow > L - 1) qrow = L - 1;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk)
-      qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
+      for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
+    }
 
     f32x16 o0, o1;  // O^T tiles: d in [0,32), [32,64); column = query (lane)
 #pragma unroll
@@ -255,10 +265,12 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(con
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
       }
       // s[r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*lh][query = lr]  (unscaled)
+      if (kt * 32 + 32 > L) {   // only the last key tile can hold padding keys (wave-uniform)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (key >= L) s[r] = -1e30f;
+        for (int r = 0; r < 16; ++r) {
+          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+          if (key >= L) s[r] = -1e30f;
+        }
       }
       float tmax = s[0];
 #pragma unroll
