@@ -184,6 +184,9 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
 //                                      converted to bf16 in place (k order of the accumulator).
 // qkv: [M][3*Hd] bf16 (q | k | v sections, heads contiguous inside a section), RoPE already applied.
 #define ATT_D 64
+#ifndef ATT_ABL
+#define ATT_ABL 0   // diagnostic builds only (tools/dbg/att_bench.hip): 1 no stores, 2 no key loop, 4 no K/V loads
+#endif
 
 // NW waves per workgroup: 4 for short sequences (5 workgroups per CU), 8 once the K/V images leave room for a
 // single workgroup per CU (L > 160: twice the waves in flight behind the same LDS bytes)
@@ -219,16 +222,28 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(con
     for (int kk = 0; kk < 4; ++kk)
       qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
   }
-  // ---- stage K (swizzled rows) and V^T; rows >= L are zero
-  for (int idx = tid; idx < Lp * 8; idx += 64 * NW) {
-    const int row = idx >> 3, c = idx & 7;
-    uint4 kv = make_uint4(0, 0, 0, 0), vv = make_uint4(0, 0, 0, 0);
-    if (row < L) {
-      kv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + hid + c * 8);
-      vv = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * hid + c * 8);
+  // ---- stage K (swizzled rows) and V; rows >= L are zero.  Four rounds of loads are requested before the first
+  // LDS write, so a 128-row sequence pays one memory latency instead of four.
+  for (int i0 = tid; i0 < Lp * 8; i0 += 64 * NW * 4) {
+    uint4 kv[4], vv[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * 64 * NW, row = idx >> 3, c = idx & 7;
+      kv[u] = make_uint4(0, 0, 0, 0);
+      vv[u] = make_uint4(0, 0, 0, 0);
+      if (row < L && !(ATT_ABL & 4)) {   // covers idx >= Lp * 8 as well (L <= Lp)
+        kv[u] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + hid + c * 8);
+        vv[u] = *reinterpret_cast<const uint4*>(base + (size_t)row * ld + 2 * hid + c * 8);
+      }
     }
-    *reinterpret_cast<uint4*>(k_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv;
-    *reinterpret_cast<uint4*>(v_lds + row * 128 + ((c ^ ((row & 3) << 1)) << 4)) = vv;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = i0 + u * 64 * NW, row = idx >> 3, c = idx & 7;
+      if (idx < Lp * 8) {
+        *reinterpret_cast<uint4*>(k_lds + row * 128 + ((c ^ ((row >> 1) & 7)) << 4)) = kv[u];
+        *reinterpret_cast<uint4*>(v_lds + row * 128 + ((c ^ ((row & 3) << 1)) << 4)) = vv[u];
+      }
+    }
   }
   __syncthreads();
   // transposed-read addressing (per 16-lane group: lane 4q+p supplies row q, columns 4p..4p+3 of a 4-key x
@@ -252,7 +267,7 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(con
     for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
     float m_run = -1e30f, l_run = 0.f;
 
-    for (int kt = 0; kt < n_tiles; ++kt) {
+    for (int kt = 0; kt < ((ATT_ABL & 2) ? 0 : n_tiles); ++kt) {
       f32x16 s;
 #pragma unroll
       for (int r = 0; r < 16; ++r) s[r] = 0.f;
@@ -309,21 +324,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(con
         o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o1, 0, 0, 0);
       }
     }
-    // ---- write O[query][d] = O^T / l ; lane owns query qt*32+lr, rows d = (r&3)+8(r>>2)+4lh (+32)
-    const int q = qt * 32 + lr;
-    if (q < L) {
-      const float inv = 1.0f / l_run;
-      bf16_t* orow = out + ((size_t)b * L + q) * hid + h * ATT_D;
+    // ---- O[query][d] = O^T / l ; lane owns query qt*32+lr, rows d = (r&3)+8(r>>2)+4lh (+32), i.e. the 8-byte
+    // halves of 16-byte chunk g (and 4+g) of its output row, the other half being in lane^32.  Stored like that,
+    // a wave's 16 store instructions visit 512 cache lines and the CU's address unit (about one line per cycle)
+    // costs the kernel a third of its time.  One v_permlane32_swap per register instead hands lane half 0 the
+    // even chunks and half 1 the odd ones, whole: 4 instructions of 16 bytes per lane.
+    const float inv = 1.0f / l_run;
+    uint32_t w0[8], w1[8];   // w[2g], w[2g+1]: this lane's half of chunk g
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const int d = 8 * g + 4 * lh;
-        uint2 p0, p1;
-        p0.x = (uint32_t)f2bf(o0[g * 4 + 0] * inv) | ((uint32_t)f2bf(o0[g * 4 + 1] * inv) << 16);
-        p0.y = (uint32_t)f2bf(o0[g * 4 + 2] * inv) | ((uint32_t)f2bf(o0[g * 4 + 3] * inv) << 16);
-        p1.x = (uint32_t)f2bf(o1[g * 4 + 0] * inv) | ((uint32_t)f2bf(o1[g * 4 + 1] * inv) << 16);
-        p1.y = (uint32_t)f2bf(o1[g * 4 + 2] * inv) | ((uint32_t)f2bf(o1[g * 4 + 3] * inv) << 16);
-        *reinterpret_cast<uint2*>(orow + d) = p0;
-        *reinterpret_cast<uint2*>(orow + 32 + d) = p1;
+    for (int g = 0; g < 4; ++g) {
+      w0[2 * g] = (uint32_t)f2bf(o0[g * 4 + 0] * inv) | ((uint32_t)f2bf(o0[g * 4 + 1] * inv) << 16);
+      w0[2 * g + 1] = (uint32_t)f2bf(o0[g * 4 + 2] * inv) | ((uint32_t)f2bf(o0[g * 4 + 3] * inv) << 16);
+      w1[2 * g] = (uint32_t)f2bf(o1[g * 4 + 0] * inv) | ((uint32_t)f2bf(o1[g * 4 + 1] * inv) << 16);
+      w1[2 * g + 1] = (uint32_t)f2bf(o1[g * 4 + 2] * inv) | ((uint32_t)f2bf(o1[g * 4 + 3] * inv) << 16);
+    }
+    // swap(X = half of chunk 2k, Y = half of chunk 2k+1): lanes 32..63 of X <-> lanes 0..31 of Y.  Afterwards the
+    // lower lanes hold chunk 2k as (X, Y) and the upper lanes chunk 2k+1 as (X, Y).
+#pragma unroll
+    for (int k = 0; k < 2; ++k)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        auto r0 = __builtin_amdgcn_permlane32_swap(w0[4 * k + j], w0[4 * k + 2 + j], false, false);
+        w0[4 * k + j] = r0[0]; w0[4 * k + 2 + j] = r0[1];
+        auto r1 = __builtin_amdgcn_permlane32_swap(w1[4 * k + j], w1[4 * k + 2 + j], false, false);
+        w1[4 * k + j] = r1[0]; w1[4 * k + 2 + j] = r1[1];
+      }
+    const int q = qt * 32 + lr;
+    if (q < L && (!(ATT_ABL & 1) || l_run == 12345.f)) {
+      bf16_t* orow = out + ((size_t)b * L + q) * hid + h * ATT_D + lh * 8;
+#pragma unroll
+      for (int k = 0; k < 2; ++k) {
+        *reinterpret_cast<uint4*>(orow + 16 * k) = make_uint4(w0[4 * k], w0[4 * k + 1], w0[4 * k + 2], w0[4 * k + 3]);
+        *reinterpret_cast<uint4*>(orow + 32 + 16 * k) = make_uint4(w1[4 * k], w1[4 * k + 1], w1[4 * k + 2], w1[4 * k + 3]);
       }
     }
   }
