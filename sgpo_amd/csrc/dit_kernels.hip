@@ -188,10 +188,10 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
 #define ATT_ABL 0   // diagnostic builds only (tools/dbg/att_bench.hip): 1 no stores, 2 no key loop, 4 no K/V loads
 #endif
 
-// NW waves per workgroup: 4 for short sequences (5 workgroups per CU), 8 once the K/V images leave room for a
-// single workgroup per CU (L > 160: twice the waves in flight behind the same LDS bytes)
+// NW waves per workgroup: 4 for short sequences (5 workgroups per CU), 8 once the K/V images leave room for two
+// workgroups per CU (L > 160: twice the waves in flight behind the same LDS bytes), 16 when only one fits (L > 320)
 template <int NW>
-__global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : 2) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
+__global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : NW == 8 ? 2 : 1) void attention_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                                          int L, int Lp, int n_heads, float scale_log2e) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hid = n_heads * ATT_D;
@@ -372,11 +372,15 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<8>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<16>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     attr_lds = lds;
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
   ProfScope prof_scope(PK_ATTENTION, stream, 4.0 * B * n_heads * (double)L * L * head_dim);
-  if (lds > 40 * 1024)
+  if (lds > 80 * 1024)   // one workgroup per CU: 16 waves cover up to 16 query tiles in one round
+    hipLaunchKernelGGL(attention_kernel<16>, dim3(B * n_heads), dim3(1024), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
+  else if (lds > 40 * 1024)
     hipLaunchKernelGGL(attention_kernel<8>, dim3(B * n_heads), dim3(512), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
   else
     hipLaunchKernelGGL(attention_kernel<4>, dim3(B * n_heads), dim3(256), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
