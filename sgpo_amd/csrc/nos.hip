@@ -45,6 +45,27 @@ __global__ __launch_bounds__(512) void nos_row_kernel(NosArgs a) {   // 8 waves 
     if (b > a.B - 1) b = a.B - 1;
     const float* sh = a.shift + (size_t)b * a.mod_stride;
     const float* sc = a.scale + (size_t)b * a.mod_stride;
+    // Unmasked rows (wave-uniform): dL/dz is 0 there, so neither p0 nor the logits of the inner steps are ever
+    // used and the gradient is the constant -w_cls / L: only the Adagrad update remains (16 H bytes, no LDS
+    // traffic).  Same bits as the full computation (0 - c == -c).  The final logits are formed for every row.
+    const bool masked = (int)a.xt[row] == a.mask_index;
+    if (MODE != NOS_FINAL && !masked) {
+#pragma unroll
+      for (int i = 0; i < PER; ++i) {
+        const int col = i * 64 + lane;
+        const size_t idx = (size_t)row * H + col;
+        if (MODE == NOS_INIT) {
+          a.delta[idx] = 0.f;
+          a.G[idx] = 0.f;
+        } else {
+          const float grad = 0.f - a.w_cls[col] * a.inv_L;
+          const float Gn = a.G[idx] + grad * grad;
+          a.G[idx] = Gn;
+          a.delta[idx] = a.delta[idx] - a.lr * grad / (sqrtf(Gn) + 1e-10f);
+        }
+      }
+      continue;
+    }
     float x[PER], y[PER], g[PER];
     float s = 0.f;
 #pragma unroll
@@ -112,10 +133,9 @@ __global__ __launch_bounds__(512) void nos_row_kernel(NosArgs a) {   // 8 waves 
       }
       continue;
     }
-    // ---- NOS_STEP: closed-form backward + Adagrad
-    const bool masked = (int)a.xt[row] == a.mask_index;
+    // ---- NOS_STEP: closed-form backward + Adagrad (masked rows only get here)
     float dx[PER];
-    if (masked) {
+    {
       float dxn[PER];
 #pragma unroll
       for (int i = 0; i < PER; ++i) dxn[i] = 0.f;
@@ -134,9 +154,6 @@ __global__ __launch_bounds__(512) void nos_row_kernel(NosArgs a) {   // 8 waves 
       const float m1 = wave_sum(s1) * (1.0f / H), m2 = wave_sum(s2) * (1.0f / H);
 #pragma unroll
       for (int i = 0; i < PER; ++i) dx[i] = rstd * (dxn[i] - m1 - y[i] * m2);
-    } else {
-#pragma unroll
-      for (int i = 0; i < PER; ++i) dx[i] = 0.f;
     }
 #pragma unroll
     for (int i = 0; i < PER; ++i) {
