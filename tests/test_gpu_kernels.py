@@ -83,10 +83,17 @@ def test_dit_forward(rt, name):
 
 @pytest.mark.parametrize('dims,B,L', [(dict(hidden=128, cond_dim=32, n_blocks=2, n_heads=2), 3, 389),
                                       (dict(hidden=512, cond_dim=128, n_blocks=2, n_heads=8), 2, 389),
-                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 161)])
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 161),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 3, 20),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 33),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 320),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 321),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 1, 512)])
 def test_dit_forward_long_sequences(rt, dims, B, L):
-    """TrpB length (389) and the first length past the 4-wave attention kernel (K/V images > 40 KB switch to 8 waves
-    per workgroup): device logits against the CPU restatement rounding to bf16 where autocast does."""
+    """TrpB length (389) and the lengths around the attention kernel's variants: a single key tile (20), idle
+    waves (33), the first length past the 4-wave kernel (161: K/V images > 40 KB switch to 8 waves per workgroup),
+    the last 8-wave and first 16-wave length (320 / 321), two full rounds of query tiles (512).  Device logits
+    against the CPU restatement rounding to bf16 where autocast does."""
     from oracle import dit as odit
     from sgpo_amd import weights as W
     sd = W.dit_synthetic_state(seed=9, vocab=31, **dims)
@@ -102,8 +109,8 @@ def test_dit_forward_long_sequences(rt, dims, B, L):
     print(f'L={L} hidden={dims["hidden"]}: dev-vs-fp32 {err:.3e}  bf16emu-vs-fp32 {err_emu:.3e}')
     assert err < 2.0 * err_emu + 2e-3 and (logits - ref16).abs().max() / scale < 1.5e-2
     # a sequence's logits do not depend on its neighbours in the batch
-    one = net.forward(x[1:2].cuda(), sigma[1:2].cuda()).cpu()
-    assert torch.equal(one[0], logits[1])
+    one = net.forward(x[B - 1:B].cuda(), sigma[B - 1:B].cuda()).cpu()
+    assert torch.equal(one[0], logits[B - 1])
 
 
 @pytest.mark.parametrize('B', [12, 36])     # M = 1428: 256x128 tiles only; M = 4284: 256x256 tiles with a ragged last tile
