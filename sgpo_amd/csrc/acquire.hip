@@ -254,7 +254,9 @@ __global__ void landscape_kernel(const float* __restrict__ table, const int64_t*
   size_t idx = 0;
   bool bad = false;
   for (int k = 0; k < n_res; ++k) {
-    const int64_t tok = tokens[(size_t)i * L + residues[k]];
+    const int pos = residues[k];
+    if (pos < 0 || pos >= L) { bad = true; continue; }   // a position outside the sequence: flagged, never read
+    const int64_t tok = tokens[(size_t)i * L + pos];
     bad |= tok < 0 || tok >= n_std;
     idx = idx * n_std + (size_t)(bad ? 0 : tok);
   }
@@ -288,6 +290,8 @@ extern "C" int sgpo_project_tokens(int64_t* tokens, const int64_t* full_seq, int
   return SGPO_OK;
 }
 
+extern "C" void sgpo_acq_destroy(sgpo_acq* a);
+
 extern "C" int sgpo_acq_create(int L, size_t capacity, int max_batch, sgpo_acq** out) {
   SGPO_REQUIRE(out && L > 0 && capacity > 0 && max_batch > 0, "acq_create: bad arguments");
   SGPO_REQUIRE(capacity + (size_t)max_batch < ACQ_REP_MASK, "acq_create: capacity + max_batch must stay below 2^24");
@@ -301,19 +305,28 @@ extern "C" int sgpo_acq_create(int L, size_t capacity, int max_batch, sgpo_acq**
   a->table = table;
   a->d.L = L;
   a->d.mask = (uint32_t)(table - 1);
-  SGPO_CHECK_HIP(hipMalloc(&a->d.slots, table * 8));
-  SGPO_CHECK_HIP(hipMalloc(&a->d.first, table * 4));
-  SGPO_CHECK_HIP(hipMalloc(&a->d.slot_round, table * 4));
-  SGPO_CHECK_HIP(hipMalloc(&a->d.store, capacity * (size_t)L));
-  SGPO_CHECK_HIP(hipMalloc(&a->d.store_round, capacity * 4));
-  SGPO_CHECK_HIP(hipMalloc(&a->slot_of, (size_t)max_batch * 4));
-  SGPO_CHECK_HIP(hipMalloc(&a->flag, (size_t)max_batch));
-  SGPO_CHECK_HIP(hipMalloc(&a->rank, (size_t)max_batch * 4));
-  SGPO_CHECK_HIP(hipMalloc(&a->counts, 16));
-  SGPO_CHECK_HIP(hipMemset(a->d.slots, 0xFF, table * 8));
-  SGPO_CHECK_HIP(hipMemset(a->d.first, 0xFF, table * 4));
-  SGPO_CHECK_HIP(hipMemset(a->d.slot_round, 0xFF, table * 4));
-  SGPO_CHECK_HIP(hipMemset(a->counts, 0, 16));
+  // a failure part-way releases what was allocated (the handle is value-initialised: unset pointers are null)
+  auto build = [&]() -> int {
+    SGPO_CHECK_HIP(hipMalloc(&a->d.slots, table * 8));
+    SGPO_CHECK_HIP(hipMalloc(&a->d.first, table * 4));
+    SGPO_CHECK_HIP(hipMalloc(&a->d.slot_round, table * 4));
+    SGPO_CHECK_HIP(hipMalloc(&a->d.store, capacity * (size_t)L));
+    SGPO_CHECK_HIP(hipMalloc(&a->d.store_round, capacity * 4));
+    SGPO_CHECK_HIP(hipMalloc(&a->slot_of, (size_t)max_batch * 4));
+    SGPO_CHECK_HIP(hipMalloc(&a->flag, (size_t)max_batch));
+    SGPO_CHECK_HIP(hipMalloc(&a->rank, (size_t)max_batch * 4));
+    SGPO_CHECK_HIP(hipMalloc(&a->counts, 16));
+    SGPO_CHECK_HIP(hipMemset(a->d.slots, 0xFF, table * 8));
+    SGPO_CHECK_HIP(hipMemset(a->d.first, 0xFF, table * 4));
+    SGPO_CHECK_HIP(hipMemset(a->d.slot_round, 0xFF, table * 4));
+    SGPO_CHECK_HIP(hipMemset(a->counts, 0, 16));
+    return SGPO_OK;
+  };
+  const int rc = build();
+  if (rc != SGPO_OK) {
+    sgpo_acq_destroy(a);
+    return rc;
+  }
   *out = a;
   return SGPO_OK;
 }
