@@ -24,3 +24,15 @@ def load_golden(name):
 @pytest.fixture(scope='session')
 def golden():
     return load_golden
+
+
+def golden_noise(g, B, L):
+    """Exp(1) noise of a golden that stores only its CPU generator seed (the full-size trajectory: 3.7 MB)."""
+    import pytest
+    import torch
+    T = int(g['T'])
+    gen = torch.Generator().manual_seed(int(g['noise_seed']))
+    es = torch.stack([torch.empty(B * L, 31).exponential_(1, generator=gen) for _ in range(T - 1)])
+    if not torch.equal(es[0, :4], g['es_first']) or float(es.double().sum()) != float(g['es_sum']):
+        pytest.skip('this torch build draws another Exp(1) stream than the one the golden was made with')
+    return es.view(T - 1, B, L, 31)

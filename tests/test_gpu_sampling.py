@@ -10,7 +10,7 @@ device path is then checked three ways, as `north_star` asks:
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import golden_noise, load_golden
 
 pytestmark = pytest.mark.gpu
 
@@ -47,14 +47,17 @@ def _build(g, T, Lq, full_seq, temp, mlp_seed):
     return net, pred, algo, sd, msd
 
 
-@pytest.mark.parametrize('tag', ['unguided', 'guided'])
+@pytest.mark.parametrize('tag', ['small_unguided', 'small_guided', 'real_guided'])
 def test_cg_teacher_forced_against_reference_trajectory(env, tag):
+    """`real_guided` is BASELINE configs 1/2 at full size: DiT 512 x 8 blocks, CreiLOV, 127 steps, temperature 0.064."""
     from oracle import cls_guidance as ocg
     from oracle import mdlm as omdlm
     from oracle import mlp as omlp
-    g = load_golden(f'cg_small_{tag}')
+    g = load_golden(f'cg_{tag}')
     T, temp = int(g['T']), float(g['temp'])
     B, Lq = g['x'].shape
+    if 'es' not in g:
+        g['es'] = golden_noise(g, B, Lq)
     full_seq = bytes(g['full_seq'].numpy().tolist()).decode()
     net, pred, algo, sd, msd = _build(g, T, Lq, full_seq, temp, int(g['mlp_seed']))
     opred = omlp.Predictor(msd)

@@ -4,7 +4,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import load_golden
+from conftest import golden_noise, load_golden
 from oracle import cls_guidance as ocg
 from oracle import dit as odit
 from oracle import mdlm as omdlm
@@ -98,3 +98,15 @@ def test_cls_guidance_inference(tag):
     torch.testing.assert_close(qg, g['qg'], rtol=2e-4, atol=1e-7)
     x = ocg.inference_mdlm(sd, B, L, int(g['T']), 28, g['es'], predictor=pred, temperature=temp)
     assert torch.equal(x, g['x'])
+
+
+def test_cls_guidance_inference_full_size():
+    """BASELINE configs 1/2 at full size (DiT 512 x 8 blocks, CreiLOV L = 119, 127 steps, temperature 0.064, B = 2):
+    the restatement reaches the reference's final tokens bit for bit and its fitness values."""
+    g = load_golden('cg_real_guided')
+    sd = _sd(g)
+    B, L = g['x'].shape
+    pred = omlp.Predictor(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=L))
+    x = ocg.inference_mdlm(sd, B, L, int(g['T']), 28, golden_noise(g, B, L), predictor=pred, temperature=float(g['temp']))
+    assert torch.equal(x, g['x'])
+    torch.testing.assert_close(pred.log_likelihood(x), g['fitness'], rtol=1e-5, atol=1e-6)

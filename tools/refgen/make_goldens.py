@@ -225,6 +225,31 @@ def gen_cg():
              full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
 
 
+def gen_cg_real():
+    """BASELINE configs 1/2 at full size: the real DiT dims, CreiLOV (L = 119), 127 reverse steps, temperature 0.064,
+    B = 2.  The Exp(1) noise of torch.multinomial (3.7 MB) is not stored: the test redraws it from the same CPU
+    generator seed and checks the stored checksum."""
+    import time
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, T, temp, noise_seed = 2, 119, 128, 0.064, 77
+    net, core, sd = build_ref_mdlm(REAL, seed=16, L=L, T=T)
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=CREILOV, residues=None))
+    pred, msd = build_ref_mlp(L, None, seed=34, full_len=L)
+    algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred, temperature=temp, device='cpu')
+    gen = torch.Generator().manual_seed(noise_seed)
+    es = torch.stack([torch.empty(B * L, 31).exponential_(1, generator=gen) for _ in range(T - 1)])
+    torch.manual_seed(noise_seed)
+    t0 = time.time()
+    with torch.no_grad():
+        x = algo.inference(num_samples=B)
+    print(f'reference inference: {time.time() - t0:.1f} s')
+    with torch.no_grad():
+        fit = pred.log_likelihood(x)
+    save('cg_real_guided', seed=16, mlp_seed=34, dims=np.array(list(REAL.values())), T=T, temp=temp,
+         noise_seed=noise_seed, es_sum=es.double().sum(), es_first=es[0, :4], x=x, fitness=fit,
+         full_seq=np.frombuffer(CREILOV.encode(), dtype=np.uint8))
+
+
 BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
 
 
@@ -721,7 +746,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
+GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
