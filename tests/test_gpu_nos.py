@@ -19,12 +19,13 @@ def env():
     return runtime
 
 
-def test_nos_denoise_against_reference(env):
+@pytest.mark.parametrize('name', ['nos_small', 'nos_real'])   # nos_real: BASELINE config 4 at full size (real DiT dims, L = 389)
+def test_nos_denoise_against_reference(env, name):
     from models.mdlm import MDLM
     from oracle import nos as onos
     from problem.protein_nos import NOSHead
     from sgpo_amd import weights as W
-    g = load_golden('nos_small')
+    g = load_golden(name)
     dims = dict(zip(DIM_KEYS, [int(v) for v in g['dims']]))
     sd = W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
     cfg = dict(model=dict(hidden_size=dims['hidden'], cond_dim=dims['cond_dim'], n_blocks=dims['n_blocks'],
@@ -37,7 +38,7 @@ def test_nos_denoise_against_reference(env):
         head.output_layer.weight.copy_(g['w_cls'])
         head.output_layer.bias.copy_(g['b_cls'])
     head = head.cuda().eval()
-    for tag in 'abc':
+    for tag in bytes(g['tags'].numpy().tolist()).decode():
         t, nsteps, lr, coef = [float(v) for v in g[f'hp_{tag}']]
         u = g[f'u_{tag}']
         net.injected_noise.append(u)
@@ -45,10 +46,14 @@ def test_nos_denoise_against_reference(env):
         p_ref = g[f'probs_{tag}']
         # the backbone is bf16 on the device: hidden-state error propagates to the probabilities
         torch.testing.assert_close(probs.cpu(), p_ref, rtol=5e-2, atol=2e-3)
-        v = p_ref / (1e-10 - (u + 1e-10).log())
-        top2 = v.topk(2, dim=-1).values
-        ok = ((top2[..., 0] - top2[..., 1]) > 5e-2 * top2[..., 0]) | (g['x'] != 28)
-        assert ok.float().mean() > 0.8
+        # tokens must agree wherever the race p / E cannot flip inside that tolerance: the reference winner's lower
+        # bound beats every other entry's upper bound (unmasked positions carry over whatever the probabilities)
+        E = 1e-10 - (u + 1e-10).log()
+        lo, hi = (p_ref * (1 - 5e-2) - 2e-3).clamp_min(0) / E, (p_ref * (1 + 5e-2) + 2e-3) / E
+        win = (p_ref / E).argmax(-1, keepdim=True)
+        ok = (lo.gather(-1, win) > hi.scatter(-1, win, 0.).max(-1, keepdim=True).values).squeeze(-1) | (g['x'] != 28)
+        print(f'{name} {tag}: {float(ok.float().mean()):.3f} of the positions are decided beyond the tolerance')
+        assert ok.float().mean() > (0.8 if name == 'nos_small' else 0.6)
         assert torch.equal(xs.cpu()[ok], g[f'xs_{tag}'][ok]), tag
         assert torch.equal(xs.cpu()[g['x'] != 28], g['x'][g['x'] != 28])      # carry-over
         # the optimised delta itself against the autograd oracle, fed the oracle's fp32 hidden state so

@@ -364,15 +364,23 @@ def gen_daps():
 def gen_nos():
     """MDLM._nos_denoise (models/mdlm.py:184-338) with the reference DITClassifier head
     (dit.py:420-515, x_emb path: mean-pool + Linear(hidden, 1))."""
+    for name, dims, B, L, seed, cases in (
+            ('nos_small', SMALL, 3, 21, 16, (('a', 100, 5, 0.5, 0.1), ('b', 3, 2, 0.5, 10.0), ('c', 64, 5, 0.5, 200.0))),
+            # BASELINE config 4 at full size: the real DiT dims, TrpB length, 5 NOS steps of size 0.5
+            ('nos_real', REAL, 2, 389, 18, (('a', 100, 5, 0.5, 1.0), ('c', 64, 5, 0.5, 200.0)))):
+        _gen_nos_case(name, dims, B, L, seed, cases)
+
+
+def _gen_nos_case(name, dims, B, L, seed, cases):
     from models.pretraining.model.mdlm.models.dit import DITClassifier
-    B, L, T = 3, 21, 128
-    net, core, sd = build_ref_mdlm(SMALL, seed=16, L=L, T=T)
-    cm = standins.to_attr(dict(classifier_model=dict(hidden_size=SMALL['hidden'], cond_dim=SMALL['cond_dim'],
-                                                     n_blocks=1, n_heads=SMALL['n_heads'], scale_by_sigma=True,
+    T = 128
+    net, core, sd = build_ref_mdlm(dims, seed=seed, L=L, T=T)
+    cm = standins.to_attr(dict(classifier_model=dict(hidden_size=dims['hidden'], cond_dim=dims['cond_dim'],
+                                                     n_blocks=1, n_heads=dims['n_heads'], scale_by_sigma=True,
                                                      dropout=0.1, pooling='mean')))
     clf = DITClassifier(cm, vocab_size=31)
     g = torch.Generator().manual_seed(44)
-    w_cls = torch.randn(1, SMALL['hidden'], generator=g) * 0.5
+    w_cls = torch.randn(1, dims['hidden'], generator=g) * 0.5
     b_cls = torch.randn(1, generator=g)
     with torch.no_grad():
         clf.output_layer.weight.copy_(w_cls)
@@ -381,8 +389,9 @@ def gen_nos():
     x = torch.randint(0, 26, (B, L), generator=g)
     x[:, ::2] = 28
     x[1, :] = 28
-    out = dict(seed=16, dims=np.array(list(SMALL.values())), T=T, x=x, w_cls=w_cls, b_cls=b_cls)
-    for tag, t, nsteps, lr, coef in (('a', 100, 5, 0.5, 0.1), ('b', 3, 2, 0.5, 10.0), ('c', 64, 5, 0.5, 200.0)):
+    out = dict(seed=seed, dims=np.array(list(dims.values())), T=T, x=x, w_cls=w_cls, b_cls=b_cls,
+               tags=np.frombuffer(''.join(c[0] for c in cases).encode(), dtype=np.uint8))
+    for tag, t, nsteps, lr, coef in cases:
         torch.manual_seed(500 + t)
         u = torch.rand(B, L, 31)
         torch.manual_seed(500 + t)
@@ -392,7 +401,7 @@ def gen_nos():
         out[f'probs_{tag}'] = probs.detach()
         out[f'u_{tag}'] = u
         out[f'hp_{tag}'] = np.array([t, nsteps, lr, coef])
-    save('nos_small', **out)
+    save(name, **out)
 
 
 def gen_oracle_ens():
