@@ -38,11 +38,17 @@ def _step_mats(Q, Q_bar, sigma, t, tn):
     return torch.eye(S) * torch.exp(ds) + torch.ones(S) / S * (1 - torch.exp(ds)), Q_bar[tn]
 
 
-def test_posterior_kernel_against_reference(rt):
-    g = load_golden('d3pm_small')
+def _tags(g, default):
+    return bytes(g['tags'].numpy().tolist()).decode() if 'tags' in g else default
+
+
+# *_real: BASELINE config 3 at full size (TrpB L = 389, real ByteNet dims behind the stored logits, 1000 MH proposals)
+@pytest.mark.parametrize('name', ['d3pm_small', 'd3pm_real'])
+def test_posterior_kernel_against_reference(rt, name):
+    g = load_golden(name)
     Q, Q_bar, sigma = _sched()
     x = g['x']
-    for tag in 'abcde':
+    for tag in _tags(g, 'abcde'):
         t, tn = int(g[f't_{tag}'][0]), int(g[f't_{tag}'][1])
         tn = None if tn < 0 else tn
         dq, qb = _step_mats(Q, Q_bar, sigma, t, tn)
@@ -59,8 +65,9 @@ def test_posterior_kernel_against_reference(rt):
         assert torch.equal(xh[ok], g[f'hard_{tag}'][ok])
 
 
-def test_q_sample_d3pm_bit_exact(rt):
-    g = load_golden('d3pm_small')
+@pytest.mark.parametrize('name', ['d3pm_small', 'd3pm_real'])
+def test_q_sample_d3pm_bit_exact(rt, name):
+    g = load_golden(name)
     Q, Q_bar, sigma = _sched()
     x = g['x']
     out = rt.q_sample_d3pm(x.cuda(), g['tq'], Q_bar.cuda().contiguous(), S, noise=g['eq'].view(x.shape[0], x.shape[1], S))
@@ -114,8 +121,9 @@ def _mh_setup(rt, g):
     return vf, [r - 1 for r in res1], msd, res1
 
 
-def test_metropolis_hastings_kernel_against_reference(rt):
-    g = load_golden('daps_small')
+@pytest.mark.parametrize('name', ['daps_small', 'daps_real'])
+def test_metropolis_hastings_kernel_against_reference(rt, name):
+    g = load_golden(name)
     vf, residues0, msd, res1 = _mh_setup(rt, g)
     L = g['x0hat'].shape[1]
     for tag in ('lo', 'hi', 'inf'):

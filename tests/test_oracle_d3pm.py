@@ -2,6 +2,7 @@
 reference import (models/d3pm.py, sampling/daps.py).  The denoiser inside is the oracle's own
 ByteNet restatement (third party upstream, parity unpinned) -- the goldens store its logits, so
 the wrapper arithmetic is pinned independently of it."""
+import pytest
 import torch
 
 from conftest import load_golden
@@ -31,12 +32,18 @@ def test_schedule_and_sigma():
     assert torch.isfinite(s32[:499]).all()
 
 
-def test_p_sample_and_q_sample():
-    g = load_golden('d3pm_small')
+def _tags(g, default):
+    return bytes(g['tags'].numpy().tolist()).decode() if 'tags' in g else default
+
+
+# *_real: BASELINE config 3 at full size (TrpB L = 389, ByteNet restatement with its real dims, 1000 MH proposals)
+@pytest.mark.parametrize('name', ['d3pm_small', 'd3pm_real'])
+def test_p_sample_and_q_sample(name):
+    g = load_golden(name)
     Q, Q_bar, sigma = _sched()
-    sd = W.bytenet_synthetic_state(seed=int(g['bn_seed']), **BN_SMALL)
+    sd = W.bytenet_synthetic_state(seed=int(g['bn_seed']), **(BN_SMALL if name == 'd3pm_small' else {}))
     x = g['x']
-    for tag in 'abcde':
+    for tag in _tags(g, 'abcde'):
         t, tn = int(g[f't_{tag}'][0]), int(g[f't_{tag}'][1])
         tn = None if tn < 0 else tn
         logits = obn.bytenet_forward(sd, x, torch.tensor([t] * x.shape[0]))
@@ -49,8 +56,9 @@ def test_p_sample_and_q_sample():
     assert torch.equal(xq, g['q_sample'])
 
 
-def test_metropolis_hasting():
-    g = load_golden('daps_small')
+@pytest.mark.parametrize('name', ['daps_small', 'daps_real'])
+def test_metropolis_hasting(name):
+    g = load_golden(name)
     res1 = [int(r) for r in g['residues']]
     msd = W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res1))
     pred = omlp.Predictor(msd, res1)           # reads the 1-indexed list raw (defect D3)

@@ -253,12 +253,12 @@ def gen_cg_real():
 BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
 
 
-def build_ref_d3pm(L, bn_seed=41):
+def build_ref_d3pm(L, bn_seed=41, bn_cfg=None):
     """Reference D3PM wrapper (models/d3pm.py) around a stand-in denoiser: the oracle's ByteNet
     restatement with small seeded weights.  Q / Q_bar come from the restated q_random_schedule."""
     import models.d3pm as ref_d3pm
     from oracle import bytenet as obn
-    sd = W.bytenet_synthetic_state(seed=bn_seed, **BN_SMALL)
+    sd = W.bytenet_synthetic_state(seed=bn_seed, **(BN_SMALL if bn_cfg is None else bn_cfg))
     net = object.__new__(ref_d3pm.D3PM)
     tok = standins.Tokenizer()
     Q_bar, Q = tok.q_random_schedule(timesteps=500)
@@ -300,6 +300,61 @@ def gen_d3pm():
         out['tq'] = tq
         out['eq'] = eq
     save('d3pm_small', **out)
+
+
+def gen_d3pm_real():
+    """BASELINE config 3 at full size, one call each: D3PM.p_sample / q_sample at the TrpB length around the
+    ByteNet restatement with its real dims (d1024 x 16 layers; third party upstream, parity unpinned: its logits are
+    stored), and DAPS.metropolis_hasting with the config's own 1000 proposals, alpha 128, beta 1000 on the 15 TrpB
+    residues."""
+    from sampling.daps import DAPS
+    N, L, S = 2, 389, 26
+    net, sd = build_ref_d3pm(L, bn_seed=43, bn_cfg={})
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, S, (N, L), generator=g)
+    out = dict(bn_seed=43, x=x, sigma=net.sigma, tags=np.frombuffer(b'bc', dtype=np.uint8))
+    with torch.no_grad():
+        for tag, t, tn in (('b', 300, 250), ('c', 499, 472)):
+            out[f'logits_{tag}'] = net.model(x, torch.tensor([t] * N))
+            out[f'soft_{tag}'] = net.p_sample(x, t, tn, hard=False)
+            torch.manual_seed(300 + t)
+            e = torch.empty(N * L, S, dtype=torch.float64).exponential_(1)
+            torch.manual_seed(300 + t)
+            out[f'hard_{tag}'] = net.p_sample(x, t, tn, hard=True)
+            out[f'e_{tag}'] = e
+            out[f't_{tag}'] = np.array([t, -1 if tn is None else tn])
+        tq = torch.tensor([3, 499])
+        torch.manual_seed(17)
+        eq = torch.empty(N * L, S).exponential_(1)
+        torch.manual_seed(17)
+        out['q_sample'] = net.q_sample(x, tq)
+        out['tq'] = tq
+        out['eq'] = eq
+    save('d3pm_real', **out)
+
+    N = 4
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq='A' * L, residues=TRPB_RES))
+    pred, msd = build_ref_mlp(len(TRPB_RES), TRPB_RES, seed=36, full_len=L)
+    algo = DAPS(net, forward_op=pred, num_steps=50, ode_steps=20, mh_steps=1000, alpha=128., max_dist=1, beta=1000,
+                data_config=dc, device='cpu')
+    n_res = len(algo.residues)
+    x0hat = torch.randint(0, S, (N, L), generator=g)
+    steps = 1000
+    out = dict(mlp_seed=36, residues=np.array(TRPB_RES), x0hat=x0hat, time_steps=algo.time_steps)
+    for tag, sig in (('lo', net.sigma[11]), ('hi', net.sigma[400]), ('inf', net.sigma[499])):
+        torch.manual_seed(55)
+        r_idx, r_val, r_u = [], [], []
+        for _ in range(steps):
+            r_idx.append(torch.randint(n_res, (N,)))
+            r_val.append(torch.randint(S, (N,)))
+            r_u.append(torch.rand(N))
+        torch.manual_seed(55)
+        with torch.no_grad():
+            xo = algo.metropolis_hasting(x0hat, pred, None, sig, steps=steps, alpha=algo.alpha)
+        out[f'mh_{tag}'] = xo
+        out[f'sigma_{tag}'] = sig
+    out['r_idx'], out['r_val'], out['r_u'] = torch.stack(r_idx), torch.stack(r_val), torch.stack(r_u)
+    save('daps_real', **out)
 
 
 def gen_daps():
@@ -755,7 +810,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, d3pm=gen_d3pm, daps=gen_daps, nos=gen_nos)
+GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
