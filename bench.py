@@ -311,7 +311,7 @@ def main():
                    ms_per_step=round(tms, 4), member_steps_per_s=round(E_m / (tms * 1e-3), 1))
     if rank == 0:
         cpu = None
-        if not a.no_cpu_baseline:
+        if not a.no_cpu_baseline and world == 1:      # reported at N = 1 only
             cpu = cpu_baseline(sd, msd)
         total_seq = world * B * a.steps
         line = {
