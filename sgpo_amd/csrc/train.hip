@@ -34,8 +34,9 @@ struct TrDev {
 };
 
 // in[b][k] of chunk c: embedding of the token at read position c, or the time embedding (c == n_read)
+template <int P1>
 __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const int64_t* x, const float* t, int B, int L,
-                            float (*in)[PAD], float (*tmp)[PAD], bool write_f) {
+                            float (*in)[P1], float (*tmp)[P1], bool write_f) {
   const int tid = threadIdx.x;
   if (c < d.n_read) {
     const float* ew = p + d.o_ew;
@@ -79,23 +80,32 @@ __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const 
   }
 }
 
+constexpr int PADV = H + 4;    // rows that are read four columns at a time (16-byte aligned)
+
 __global__ __launch_bounds__(256) void tr_fwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
-  __shared__ float in[TB][PAD], ws[H][PAD];
+  __shared__ __attribute__((aligned(16))) float in[TB][PADV], wt[H][PADV];   // wt[k][o]: the weight chunk transposed
   const int c = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
   const float* p = d.params + (size_t)e * d.P;
-  chunk_input(d, p, e, c, x, t, B, L, in, ws, true);
+  chunk_input(d, p, e, c, x, t, B, L, in, wt, true);
   __syncthreads();
   const float* w0 = p + d.o_w0 + (size_t)c * H;
-  for (int idx = tid; idx < H * H; idx += 256) ws[idx >> 6][idx & 63] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
+  for (int idx = tid; idx < H * H; idx += 256) wt[idx & 63][idx >> 6] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
   __syncthreads();
   const int o = tid & 63, bg = tid >> 6;
   float acc[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  for (int k = 0; k < H; ++k) {
-    const float w = ws[o][k];
+  // the batch rows are broadcast reads, four k at a time; per accumulator the k order is unchanged
+  for (int k = 0; k < H; k += 4) {
+    const float wa = wt[k][o], wb = wt[k + 1][o], wc = wt[k + 2][o], wd = wt[k + 3][o];
 #pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[bg * 16 + j][k], w, acc[j]);
+    for (int j = 0; j < 16; ++j) {
+      const float4 v = *reinterpret_cast<const float4*>(&in[bg * 16 + j][k]);
+      acc[j] = fmaf(v.x, wa, acc[j]);
+      acc[j] = fmaf(v.y, wb, acc[j]);
+      acc[j] = fmaf(v.z, wc, acc[j]);
+      acc[j] = fmaf(v.w, wd, acc[j]);
+    }
   }
   float* out = d.part_h + (((size_t)e * d.C + c) * TB) * H;
 #pragma unroll
