@@ -49,22 +49,35 @@ def train_classifier_ensemble(classifiers, model, dataloader, train_config, save
         generator = torch.Generator(device=device)
         generator.manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
     T = int(model.timestep) if time_conditioned else 1
+    # Batches are prepared a group at a time (gather, timesteps, q_sample, project_fn over up to 64 batches per member
+    # in one call each), so that a step costs a slice and the five training launches instead of a dozen small torch
+    # kernels.  Every sequence still gets its own timestep and noise, every member its own order.
+    group = 64 * bs
     for _ in range(int(n_epochs)):
         perm = torch.stack([torch.randperm(n, device=device, generator=generator) for _ in range(E)])   # shuffle=True
-        for i in range(0, n, bs):
-            idx = perm[:, i:i + bs]                                   # (E, B)
-            B = idx.shape[1]
-            x = X[idx]                                                # (E, B, L)
+        for g0 in range(0, n, group):
+            idx = perm[:, g0:g0 + group]                              # (E, G)
+            G = idx.shape[1]
+            x = X[idx]                                                # (E, G, L)
             y = Y[idx]
             if time_conditioned:
-                t = torch.randint(0, T, (E, B), device=device, generator=generator)       # train_classifier.py:36
-                xt = model.q_sample(x.reshape(E * B, Lq), t.reshape(E * B)).reshape(E, B, Lq)   # :13
+                t = torch.randint(0, T, (E, G), device=device, generator=generator)       # train_classifier.py:36
+                xt = model.q_sample(x.reshape(E * G, Lq), t.reshape(E * G)).reshape(E, G, Lq)   # :13
             else:
-                t = torch.zeros(E, B, dtype=torch.int64, device=device)                   # :38
+                t = torch.zeros(E, G, dtype=torch.int64, device=device)                   # :38
                 xt = x
             if project_fn is not None:
                 xt = project_fn(xt)                                                       # :14
-            trainer.step(xt, t.float(), y, lr=lr)
+            tf = t.float()
+            nb = G // bs                                              # full batches, laid out (batch, member, row)
+            if nb:
+                xb = xt[:, :nb * bs].reshape(E, nb, bs, Lq).transpose(0, 1).contiguous()
+                tb = tf[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
+                yb = y[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
+                for j in range(nb):
+                    trainer.step(xb[j], tb[j], yb[j], lr=lr)
+            if G > nb * bs:                                           # the ragged last batch (drop_last=False)
+                trainer.step(xt[:, nb * bs:].contiguous(), tf[:, nb * bs:].contiguous(), y[:, nb * bs:].contiguous(), lr=lr)
     for c, sd in zip(classifiers, trainer.state_dicts()):
         c.model.load_state_dict(sd)
     if save_dir is not None:
