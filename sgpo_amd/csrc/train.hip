@@ -120,7 +120,15 @@ __global__ void tr_reduce(TrDev d, int B) {
   if (b >= B) return;
   float* ph = d.part_h + (size_t)e * d.C * TB * H;
   float s = d.params[(size_t)e * d.P + d.o_b0 + o];
-  for (int c = 0; c < d.C; ++c) s += ph[(size_t)c * TB * H + bo];
+  int c = 0;
+  for (; c + 8 <= d.C; c += 8) {   // eight loads in flight, adds in chunk order
+    float v8[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v8[u] = ph[(size_t)(c + u) * TB * H + bo];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) s += v8[u];
+  }
+  for (; c < d.C; ++c) s += ph[(size_t)c * TB * H + bo];
   ph[bo] = s;
 }
 
@@ -315,16 +323,22 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
     grad_in(dz, dh, ws, in, false, B);   // d(embedding of the token at this position)
     // through the embedder: per-token sums in batch order (deterministic), bias = sum over the batch
     float* pe = d.part_e + ((size_t)e * d.n_read + c) * 32 * H;
-    if (tid < H) {
-      float bsum = 0.f;
-      for (int s = 0; s < 31; ++s) in[s][tid] = 0.f;    // reuse `in` as the [token][k] accumulator (A <= 31)
+    {
+      // thread (k, q) keeps the sums of tokens 8q .. 8q+7 in registers and walks the batch in order: the same adds in
+      // the same order as a per-token accumulator (adding 0.0f to the others changes no bit), without a serial
+      // read-modify-write chain through LDS on 64 threads.  Slot 31 (no token: A <= 31) is the bias row.
+      const int k = tid & 63, q = tid >> 6;
+      float acc[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) acc[u] = 0.f;
       for (int b = 0; b < B; ++b) {
-        const float v = dz[b][tid];
-        in[toks[b]][tid] += v;
-        bsum += v;
+        const float v = dz[b][k];
+        const int tk = toks[b] - 8 * q;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) acc[u] += (tk == u || (q == 3 && u == 7)) ? v : 0.f;
       }
-      for (int s = 0; s < 31; ++s) pe[s * H + tid] = in[s][tid];
-      pe[31 * H + tid] = bsum;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) pe[(8 * q + u) * H + k] = acc[u];
     }
   } else {
     // time chunk: dz holds the Fourier features f[b][k]; d temb[b][j] = sum_o dh[b][o] W0[o][j]
@@ -347,7 +361,16 @@ __global__ void tr_adam(TrDev d, float lr_over_bc1, float bc2_sqrt, float beta1,
     if (q < d.o_eb) { k = (q - d.o_ew) / d.A; row = (q - d.o_ew) % d.A; }
     else { k = q - d.o_eb; row = 31; }
     gr = 0.f;
-    for (int c = 0; c < d.n_read; ++c) gr += pe[((size_t)c * 32 + row) * H + k];
+    // loads eight positions ahead of the (ordered) adds: the chain is otherwise one memory latency per term
+    int c = 0;
+    for (; c + 8 <= d.n_read; c += 8) {
+      float v8[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v8[u] = pe[((size_t)(c + u) * 32 + row) * H + k];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) gr += v8[u];
+    }
+    for (; c < d.n_read; ++c) gr += pe[((size_t)c * 32 + row) * H + k];
   } else {
     gr = d.grads[i];
   }
