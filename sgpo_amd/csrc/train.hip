@@ -59,23 +59,39 @@ __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const 
       float f = 0.f;
       if (b < B) {
         // GaussianFourierProjection (problem/protein.py:54-56): x*W*2*pi, cat(sin, cos)
-        const float arg = t[(size_t)e * B + b] * tw[j & 31] * 2.0f * 3.14159274101257324f;
-        f = (j < 32) ? sinf(arg) : cosf(arg);
-        if (write_f) d.fbuf[((size_t)e * TB + b) * H + j] = f;
+        if (write_f) {
+          const float arg = t[(size_t)e * B + b] * tw[j & 31] * 2.0f * 3.14159274101257324f;
+          f = (j < 32) ? sinf(arg) : cosf(arg);
+          d.fbuf[((size_t)e * TB + b) * H + j] = f;
+        } else {
+          f = d.fbuf[((size_t)e * TB + b) * H + j];   // the backward pass reads what the forward pass stored
+        }
       }
       tmp[b][j] = f;
     }
-    __syncthreads();
+    // Linear(64, 64) of the time embedder.  Its weight goes through `in` (row j read by lane j) before `in` takes
+    // the result: read straight from memory, lane j walking row j is 64 cache lines per load instruction, and the one
+    // workgroup per member that owns this chunk would set the kernel's duration.
     const float* w = p + d.o_t1w;
     const float* bb = p + d.o_t1b;
-    for (int idx = tid; idx < TB * H; idx += 256) {
-      const int b = idx >> 6, j = idx & 63;
-      float acc = 0.f;
+    for (int idx = tid; idx < H * H; idx += 256) in[idx >> 6][idx & 63] = w[idx];
+    __syncthreads();
+    float acc[TB * H / 256];
+#pragma unroll
+    for (int it = 0; it < TB * H / 256; ++it) {
+      const int idx = tid + it * 256, b = idx >> 6, j = idx & 63;
+      float a = 0.f;
       if (b < B) {
-        acc = bb[j];
-        for (int k = 0; k < H; ++k) acc = fmaf(w[j * H + k], tmp[b][k], acc);
+        a = bb[j];
+        for (int k = 0; k < H; ++k) a = fmaf(in[j][k], tmp[b][k], a);
       }
-      in[b][j] = acc;
+      acc[it] = a;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < TB * H / 256; ++it) {
+      const int idx = tid + it * 256;
+      in[idx >> 6][idx & 63] = acc[it];
     }
   }
 }
@@ -84,7 +100,7 @@ constexpr int PADV = H + 4;    // rows that are read four columns at a time (16-
 
 __global__ __launch_bounds__(256) void tr_fwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
   __shared__ __attribute__((aligned(16))) float in[TB][PADV], wt[H][PADV];   // wt[k][o]: the weight chunk transposed
-  const int c = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+  const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
   chunk_input(d, p, e, c, x, t, B, L, in, wt, true);
   __syncthreads();
@@ -279,7 +295,7 @@ __global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__
 __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
   __shared__ float in[TB][PAD], ws[H][PAD], dh[TB][PAD], dz[TB][PAD];
   __shared__ int toks[TB];
-  const int c = blockIdx.x, e = blockIdx.y, tid = threadIdx.x;
+  const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
   float* g = d.grads + (size_t)e * d.P;
   chunk_input(d, p, e, c, x, t, B, L, in, ws, false);   // for the time chunk ws holds the Fourier features meanwhile
