@@ -293,17 +293,13 @@ __global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__
 }
 
 __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
-  __shared__ float in[TB][PAD], ws[H][PAD], dh[TB][PAD], dz[TB][PAD];
+  __shared__ float in[TB][PAD], ws[H][PAD], dh[TB][PAD];   // 50 KB: three workgroups per CU
   __shared__ int toks[TB];
   const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
   float* g = d.grads + (size_t)e * d.P;
   chunk_input(d, p, e, c, x, t, B, L, in, ws, false);   // for the time chunk ws holds the Fourier features meanwhile
   __syncthreads();
-  if (c == d.n_read) {   // keep the Fourier features: dz of this chunk is d(time embedding)
-    for (int idx = tid; idx < TB * H; idx += 256) dz[idx >> 6][idx & 63] = ws[idx >> 6][idx & 63];
-    __syncthreads();
-  }
   const float* w0 = p + d.o_w0 + (size_t)c * H;
   const float* dhg = d.dh + (size_t)e * TB * H;
   for (int idx = tid; idx < H * H; idx += 256) {
@@ -336,7 +332,7 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
   }
   if (c < d.n_read) {
     __syncthreads();
-    grad_in(dz, dh, ws, in, false, B);   // d(embedding of the token at this position)
+    grad_in(in, dh, ws, in, false, B);   // in := d(embedding of the token at this position)
     // through the embedder: per-token sums in batch order (deterministic), bias = sum over the batch
     float* pe = d.part_e + ((size_t)e * d.n_read + c) * 32 * H;
     {
@@ -348,7 +344,7 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
 #pragma unroll
       for (int u = 0; u < 8; ++u) acc[u] = 0.f;
       for (int b = 0; b < B; ++b) {
-        const float v = dz[b][k];
+        const float v = in[b][k];
         const int tk = toks[b] - 8 * q;
 #pragma unroll
         for (int u = 0; u < 8; ++u) acc[u] += (tk == u || (q == 3 && u == 7)) ? v : 0.f;
@@ -357,10 +353,30 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
       for (int u = 0; u < 8; ++u) pe[(8 * q + u) * H + k] = acc[u];
     }
   } else {
-    // time chunk: dz holds the Fourier features f[b][k]; d temb[b][j] = sum_o dh[b][o] W0[o][j]
+    // time chunk: d temb[b][j] = sum_o dh[b][o] W0[o][j]
     __syncthreads();
     grad_in(in, dh, ws, in, false, B);   // in := d temb  (grad_in reads dh/ws only, then overwrites `in`)
-    grad_w(g + d.o_t1w, g + d.o_t1b, in, dz, B);
+    // d t1.weight[j][k] = sum_b dtemb[b][j] f[b][k]: the Fourier features come back from where tr_fwd0 stored them
+    {
+      const float* f = d.fbuf + (size_t)e * TB * H;
+      const int k = tid & 63, og = tid >> 6;
+      float acc[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) acc[j] = 0.f;
+      for (int b = 0; b < B; ++b) {
+        const float av = f[b * H + k];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[b][og * 16 + j], av, acc[j]);
+      }
+      float* dW = g + d.o_t1w;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) dW[(og * 16 + j) * H + k] = acc[j];
+      if (tid < H) {
+        float sb = 0.f;
+        for (int b = 0; b < B; ++b) sb += in[b][tid];
+        g[d.o_t1b + tid] = sb;
+      }
+    }
   }
 }
 
