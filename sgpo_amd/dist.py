@@ -76,9 +76,14 @@ def sharded_inference(algo, num_samples, seed, rank=None, world=None, score_fn=N
     if hasattr(algo.net, 'global_batch'):
         algo.net.global_batch = num_samples          # NOS: KLDivLoss(batchmean) divides by the unsharded batch
     try:
-        x = algo.inference(num_samples=hi - lo, **kw)
+        if hi > lo:
+            x = algo.inference(num_samples=hi - lo, **kw)
+        else:   # more ranks than samples: this rank contributes no rows (the kernels take no empty batch)
+            x = torch.empty(0, int(algo.net.length), dtype=torch.int64, device=getattr(algo, 'device', None) or 'cpu')
     finally:
         if hasattr(algo.net, 'global_batch'):
             algo.net.global_batch = None
-    s = score_fn(x) if score_fn is not None else None
+    s = None
+    if score_fn is not None:
+        s = score_fn(x) if hi > lo else torch.empty(0, dtype=torch.float32, device=x.device)
     return gather_samples(x, s)

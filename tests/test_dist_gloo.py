@@ -8,7 +8,7 @@ import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
 
-from sgpo_amd.dist import gather_samples, shard_bounds
+from sgpo_amd.dist import gather_samples, shard_bounds, sharded_inference
 
 
 def test_shard_bounds_partition():
@@ -29,6 +29,27 @@ def _free_port():
     return p
 
 
+class _StubNet:
+    length = 13
+    global_batch = None
+
+    def reseed(self, seed, row_offset):
+        self.seen = (seed, row_offset)
+
+
+class _StubAlgo:
+    """Returns the rows of a fixed 'global batch' that the reseed call selected, like a shard-invariant sampler."""
+    device = 'cpu'
+
+    def __init__(self, full):
+        self.net, self.full = _StubNet(), full
+
+    def inference(self, num_samples):
+        assert num_samples > 0 and self.net.global_batch == self.full.shape[0]
+        lo = self.net.seen[1]
+        return self.full[lo:lo + num_samples]
+
+
 def _worker(rank, world, port, n_rows, q):
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group('gloo', rank=rank, world_size=world)
@@ -39,6 +60,10 @@ def _worker(rank, world, port, n_rows, q):
         score = full.float().sum(1)
         t, s = gather_samples(full[lo:hi], score[lo:hi])
         ok = bool(t.dtype == torch.uint8 and torch.equal(t.long(), full) and torch.equal(s, score))
+        # the same through sharded_inference with a stub sampler (incl. a rank whose shard is empty: n_rows < world)
+        algo = _StubAlgo(full)
+        t2, s2 = sharded_inference(algo, n_rows, seed=5, score_fn=lambda x: x.float().sum(1))
+        ok = ok and bool(torch.equal(t2.long(), full) and torch.equal(s2, score) and algo.net.seen == (5, lo))
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()
@@ -46,7 +71,7 @@ def _worker(rank, world, port, n_rows, q):
 
 def test_gather_samples_world2_ragged():
     world = 2
-    for n_rows in (10, 7):      # even and ragged shards
+    for n_rows in (10, 7, 1):      # even and ragged shards, and fewer rows than ranks
         port = _free_port()
         ctx = mp.get_context('spawn')
         q = ctx.Queue()
