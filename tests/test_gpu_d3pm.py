@@ -65,6 +65,28 @@ def test_posterior_kernel_against_reference(rt, name):
         assert torch.equal(xh[ok], g[f'hard_{tag}'][ok])
 
 
+@pytest.mark.parametrize('N,Lq,t,tn', [(1, 1, 300, None), (3, 7, 499, 472), (2, 389, 26, 0), (1, 600, 1, None), (5, 33, 250, 200)])
+def test_posterior_shape_sweep(rt, N, Lq, t, tn):
+    """One position, lengths off every tile size, both branches (Q step, analytic t_next step) and the infinite sigma:
+    fp64 posterior and hard tokens against the restatement on random logits and injected Exp(1) noise."""
+    from oracle import d3pm as od3pm
+    Q, Q_bar, sigma = _sched()
+    g = torch.Generator().manual_seed(N * 1000 + Lq)
+    logits = torch.randn(N, Lq, 31, generator=g) * 2
+    x = torch.randint(0, S, (N, Lq), generator=g)
+    e = torch.empty(N * Lq, S, dtype=torch.float64).exponential_(1, generator=g)
+    p_ref = od3pm.p_sample(logits, x, t, tn, Q, Q_bar, sigma, S, hard=False)
+    x_ref = od3pm.p_sample(logits, x, t, tn, Q, Q_bar, sigma, S, e=e)
+    dq, qb = _step_mats(Q, Q_bar, sigma, t, tn)
+    p = rt.reverse_step_d3pm(logits.cuda(), x.cuda(), dq, qb, S, hard=False).cpu()
+    torch.testing.assert_close(p, p_ref, rtol=1e-5, atol=1e-12)
+    xh = rt.reverse_step_d3pm(logits.cuda(), x.cuda(), dq, qb, S, hard=True, noise=e.view(N, Lq, S)).cpu()
+    v = p_ref / e.view(N, Lq, S)
+    top2 = v.topk(2, dim=-1).values
+    ok = (top2[..., 0] - top2[..., 1]) > 1e-4 * top2[..., 0]
+    assert ok.float().mean() > 0.9 and torch.equal(xh[ok], x_ref[ok])
+
+
 @pytest.mark.parametrize('name', ['d3pm_small', 'd3pm_real'])
 def test_q_sample_d3pm_bit_exact(rt, name):
     g = load_golden(name)

@@ -179,6 +179,41 @@ def test_reverse_step_mdlm_soft_and_hard(rt):
         assert torch.equal(xh.cpu()[ok], g[f'hard_t{t}'][ok])
 
 
+@pytest.mark.parametrize('B,Lq,K', [(1, 1, 2), (3, 7, 5), (2, 64, 26), (17, 119, 31), (2, 389, 32), (1, 600, 31), (5, 33, 31)])
+def test_reverse_step_shape_sweep(rt, B, Lq, K):
+    """Ragged and extreme shapes (one position, two letters, the full 32-letter limit, lengths off every tile size):
+    MDLM soft / hard and UDLM soft / hard against the restatement on the same random logits and injected noise."""
+    from oracle import mdlm as omdlm
+    from sgpo_amd import _lib as L
+    g = torch.Generator().manual_seed(B * 1000 + Lq * 10 + K)
+    mask = K - 1 if K < 31 else 28
+    logits = torch.randn(B, Lq, K, generator=g) * 3
+    x = torch.randint(0, K, (B, Lq), generator=g)
+    x[torch.rand(B, Lq, generator=g) < 0.5] = mask
+    u = torch.rand(B, Lq, K, generator=g)
+    T, t = 128, 77
+    mt, ms, _ = omdlm.move_chances(t, T, B)
+    mtf, msf = float(mt[0, 0, 0]), float(ms[0, 0, 0])
+    logp = omdlm.subs_parameterization(logits, x, mask)
+    q_ref = omdlm.p_sample(None, x, t, T, mask, hard=False, log_p_x0=logp)
+    x_ref = omdlm.p_sample(None, x, t, T, mask, hard=True, u=u, log_p_x0=logp)
+    _, q = rt.reverse_step_mdlm(logits.cuda(), x.cuda(), mtf, msf, mask, L.STEP_SOFT)
+    torch.testing.assert_close(q.cpu(), q_ref, rtol=1e-4, atol=1e-7)
+    xh, _ = rt.reverse_step_mdlm(logits.cuda(), x.cuda(), mtf, msf, mask, L.STEP_HARD, noise=u.cuda())
+    ok = _margin_ok(q_ref, 1e-10 - (u + 1e-10).log(), None) | (x != mask)
+    assert torch.equal(xh.cpu()[ok], x_ref[ok]) and ok.float().mean() > 0.9
+    assert torch.equal(xh.cpu()[x != mask], x[x != mask])                       # carry-over
+    # UDLM (uniform diffusion, d3pm parameterisation)
+    logp_u = omdlm.d3pm_parameterization(logits, mask)
+    qu_ref = omdlm.p_sample(None, x, t, T, mask, diffusion='uniform', hard=False, log_p_x0=logp_u)
+    xu_ref = omdlm.p_sample(None, x, t, T, mask, diffusion='uniform', hard=True, u=u, log_p_x0=logp_u)
+    _, qu = rt.reverse_step_udlm(logits.cuda(), x.cuda(), mtf, msf, L.STEP_SOFT)
+    torch.testing.assert_close(qu.cpu(), qu_ref, rtol=2e-4, atol=1e-7)
+    xuh, _ = rt.reverse_step_udlm(logits.cuda(), x.cuda(), mtf, msf, L.STEP_HARD, noise=u.cuda())
+    oku = _margin_ok(qu_ref, 1e-10 - (u + 1e-10).log(), None)
+    assert torch.equal(xuh.cpu()[oku], xu_ref[oku]) and oku.float().mean() > 0.9
+
+
 def test_reverse_step_udlm(rt):
     from oracle import dit as odit
     from oracle import mdlm as omdlm
