@@ -275,6 +275,32 @@ def test_mlp_forward_and_jump_ratios(rt):
             assert float((lpj - lp.view(2, 1, 1))[:, others, :].abs().max()) < 1e-5
 
 
+@pytest.mark.parametrize('B,Lq,read_pos,S', [(1, 1, [0], 2), (2, 9, [8], 31), (3, 40, [0, 39], 26), (1, 389, list(range(0, 389, 26)), 26),
+                                             (70, 23, list(range(23)), 31), (5, 64, list(range(64)), 20)])
+def test_value_function_shape_sweep(rt, B, Lq, read_pos, S):
+    """One residue, one sequence, a batch that is no multiple of the tile, read positions at both ends of the
+    sequence: f(x, t), f(x) and the S x n_read jump log-ratios against the materialised formulation of the reference."""
+    from oracle import mdlm as omdlm
+    from oracle import mlp as omlp
+    from sgpo_amd import weights as W
+    sd = W.mlp_synthetic_state(seed=7 + Lq, n_residues=len(read_pos))
+    vf = rt.MlpValueFunction(sd, read_pos)
+    pred = omlp.Predictor(sd, read_pos)
+    g = torch.Generator().manual_seed(B + Lq)
+    x = torch.randint(0, S, (B, Lq), generator=g)
+    t = torch.randint(0, 128, (B,), generator=g).float()
+    torch.testing.assert_close(vf.forward(x.cuda(), t.cuda()).cpu(), pred(x, t).squeeze(-1), rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(vf.forward(x.cuda(), None).cpu(), pred.log_likelihood(x), rtol=1e-4, atol=1e-5)
+    tt = 17.0
+    lp = pred(x, tt * torch.ones(B))
+    xj = omdlm.get_all_jump_transitions(x, S)
+    lpj = pred(xj, tt * torch.ones(xj.shape[0])).view(B, Lq, S)
+    ref = (lpj - lp.view(B, 1, 1))[:, read_pos, :]
+    got = vf.jump_log_ratios(x.cuda(), tt, S).cpu()
+    torch.testing.assert_close(got, ref, rtol=1e-4, atol=2e-5)
+    assert float(got[torch.arange(B)[:, None], torch.arange(len(read_pos))[None, :], x[:, read_pos]].abs().max()) == 0.0   # s = x_d
+
+
 def test_absorbing_jump_ratios_skip_only_zero_rate_entries(rt):
     """sgpo_guidance_ratio_mlp_absorbing: bit-identical to the full kernel at masked positions and in the
     mask column; 0 elsewhere; and the guided step (whose prior is 0 at the skipped entries) gives the
