@@ -73,6 +73,39 @@ def test_nos_denoise_against_reference(env, name):
         assert torch.equal(xs2.cpu()[ok], g[f'xs_{tag}'][ok])
 
 
+def test_nos_hidden_256_against_oracle(env):
+    """The third supported width (128 and 512 have goldens): closed-form backward + Adagrad on the device against the
+    autograd restatement, both from the restatement's fp32 hidden state."""
+    from models.mdlm import MDLM
+    from oracle import dit as odit
+    from oracle import nos as onos
+    from sgpo_amd import runtime as rt
+    from sgpo_amd import weights as W
+    dims = dict(hidden=256, cond_dim=64, n_blocks=1, n_heads=4)
+    sd = W.dit_synthetic_state(seed=23, vocab=31, **dims)
+    cfg = dict(model=dict(hidden_size=256, cond_dim=64, n_blocks=1, n_heads=4))
+    B, Lq, T = 3, 45, 128
+    net = MDLM('synthetic', cfg, None, num_steps=T, seq_len=Lq, device='cuda:0', state_dict=sd)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, 26, (B, Lq), generator=g)
+    x[:, ::2] = 28
+    x[2, :] = 7                                              # a row without masked positions
+    w_cls, b_cls = torch.randn(1, 256, generator=g) * 0.5, torch.randn(1, generator=g)
+    u = torch.rand(B, Lq, 31, generator=g)
+    t, nsteps, lr, coef = 90, 4, 0.5, 50.0
+    xs_ref, p_ref, d_ref = onos.nos_denoise(sd, w_cls, b_cls, x, t, T, 28, nsteps, lr, coef, u)
+    _, hs = odit.dit_forward(sd, x, torch.zeros(B), return_hidden_states=True)
+    mt, ms, _ = net._move_chances(t)
+    xs, p, d = rt.nos_denoise(net.net, x.cuda(), w_cls, nsteps, lr, coef, mt, ms, 28, want_delta=True, noise=u, hidden_in=hs[-1])
+    assert float((d.cpu() - d_ref).abs().max()) / float(d_ref.abs().max()) < 2e-3
+    torch.testing.assert_close(p.cpu(), p_ref, rtol=1e-3, atol=1e-6)
+    E = 1e-10 - (u + 1e-10).log()
+    top2 = (p_ref / E).topk(2, dim=-1).values
+    ok = ((top2[..., 0] - top2[..., 1]) > 1e-2 * top2[..., 0]) | (x != 28)
+    assert ok.float().mean() > 0.9 and torch.equal(xs.cpu()[ok], xs_ref[ok])
+    assert torch.equal(xs.cpu()[2], x[2])
+
+
 def test_nos_sampler_loop(env):
     from models.mdlm import MDLM
     from problem.protein_nos import NOSHead
