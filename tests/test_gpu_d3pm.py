@@ -160,6 +160,31 @@ def test_metropolis_hastings_kernel_against_reference(rt, name):
     assert torch.equal(out.cpu(), g['x0hat'])
 
 
+@pytest.mark.parametrize('N,Lq,res1,steps', [(1, 5, [3], 40), (70, 30, [1, 2, 30], 200), (3, 389, [117, 118, 119, 162, 166, 301], 500)])
+def test_mh_shape_sweep(rt, N, Lq, res1, steps):
+    """One chain on one residue, more chains than a workgroup holds, the last position of the sequence as a residue:
+    chains with injected proposals against the restatement, token for token."""
+    from oracle import daps as odaps
+    from oracle import mlp as omlp
+    from sgpo_amd import weights as W
+    msd = W.mlp_synthetic_state(seed=60 + N, n_residues=len(res1))
+    vf = rt.MlpValueFunction(msd, res1)                     # reads the raw 1-indexed list (defect D3)
+    pred = omlp.Predictor(msd, res1)
+    residues0 = [r - 1 for r in res1]
+    gen = torch.Generator().manual_seed(N + steps)
+    x0 = torch.randint(0, S, (N, Lq + 1), generator=gen)    # one extra column: the raw list may name position Lq
+    r_idx = torch.randint(len(residues0), (steps, N), generator=gen)
+    r_val = torch.randint(S, (steps, N), generator=gen)
+    r_u = torch.rand(steps, N, generator=gen)
+    for sigma, alpha in ((torch.tensor(0.5), 128.), (torch.tensor(float('inf')), 4.)):
+        ref = odaps.metropolis_hasting(x0, pred.log_likelihood, sigma, steps, alpha, 1000, residues0, S, Lq + 1, r_idx, r_val, r_u)
+        a = (1 - torch.exp(-sigma / 1000)) * (1 - 1 / S)
+        la, l1a = float(torch.log(a + 1e-5)), float(torch.log(1 - a))
+        out = rt.daps_mh(vf, x0.cuda(), residues0, S, la, l1a, alpha, steps, r_idx=r_idx, r_val=r_val, r_u=r_u)
+        assert torch.equal(out.cpu(), ref)
+    assert (ref != x0).any()
+
+
 def test_mh_longer_chain_vs_oracle_and_philox(rt):
     """1000-step chains: injected noise vs the oracle; Philox mode only moves the mutable residues."""
     from oracle import daps as odaps

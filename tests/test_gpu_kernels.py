@@ -88,7 +88,8 @@ def test_dit_forward(rt, name):
                                       (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 33),
                                       (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 320),
                                       (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 321),
-                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 1, 512)])
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 1, 512),
+                                      (dict(hidden=256, cond_dim=64, n_blocks=2, n_heads=4), 2, 50)])   # a width between the two with goldens
 def test_dit_forward_long_sequences(rt, dims, B, L):
     """TrpB length (389) and the lengths around the attention kernel's variants: a single key tile (20), idle
     waves (33), the first length past the 4-wave kernel (161: K/V images > 40 KB switch to 8 waves per workgroup),
