@@ -389,7 +389,7 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
 }
 
 int launch_embed(const int64_t* tok, const float* emb, float* x, int M, int H, int vocab, hipStream_t stream) {
-  ProfScope prof_scope(PK_EMBED, stream, (double)M * H * 8.0);
+  ProfScope prof_scope(PK_EMBED, stream, (double)M * (H * 4.0 + 8.0));   // fp32 row written, one int64 token read (the table stays in cache)
   hipLaunchKernelGGL(embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tok, emb, x, M, H, vocab);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
