@@ -193,6 +193,31 @@ def main():
                 kernels[lib.sgpo_prof_kind_name(k).decode()] = dict(
                     total_ms=round(ms[k], 3), launches=int(cnt[k]), avg_us=round(1e3 * ms[k] / cnt[k], 2),
                     share=round(ms[k] / tot, 4), work_per_launch=work[k] / cnt[k])
+        # every kernel against its own roof: the binding one of (flops / MFMA peak, algorithmic bytes / HBM peak)
+        M_rows, Hd = B * 119, 512
+        for kname, kd in kernels.items():
+            t_s = kd['avg_us'] * 1e-6
+            flops = nbytes = None
+            if kname.startswith('gemm'):
+                flops, nbytes = kd['work_per_launch'], gemm_algorithmic_bytes(kname, B)
+                if nbytes is None and 'BIAS_F32' in kname:          # vocabulary head: bf16 rows in, 31 fp32 logits out
+                    nbytes = M_rows * Hd * 2 + M_rows * 31 * 4
+            elif kname.startswith('attention'):
+                flops, nbytes = kd['work_per_launch'], M_rows * Hd * 2 * 4   # q, k, v read, output written (bf16)
+            elif kname.startswith('mlp_jump'):
+                kd['roof'] = dict(bound='fp32 mfma', achieved=round(kd['work_per_launch'] / t_s / 1e12, 1), peak=157.3,
+                                  unit='TFLOP/s', frac=round(kd['work_per_launch'] / t_s / 1e12 / 157.3, 4))
+                continue
+            else:
+                nbytes = kd['work_per_launch']
+            t_m = flops / (MFMA_BF16_PEAK_TFLOPS * 1e12) if flops else 0.0
+            t_h = nbytes / (HBM_PEAK_GBS * 1e9) if nbytes else 0.0
+            if t_h >= t_m:
+                kd['roof'] = dict(bound='hbm', achieved=round(nbytes / t_s / 1e9, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                                  frac=round(nbytes / t_s / 1e9 / HBM_PEAK_GBS, 4))
+            else:
+                kd['roof'] = dict(bound='mfma', achieved=round(flops / t_s / 1e12, 1), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                                  frac=round(flops / t_s / 1e12 / MFMA_BF16_PEAK_TFLOPS, 4))
         dom = max(range(n), key=lambda k: ms[k])
         name = lib.sgpo_prof_kind_name(dom).decode()
         is_mfma = name.startswith('gemm') or name.startswith('attention') or name.startswith('mlp_jump')
