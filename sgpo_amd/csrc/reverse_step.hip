@@ -27,6 +27,49 @@ __device__ __forceinline__ int half_argmax(float v, int k) {
   return k;
 }
 
+// as noise_denominator, the Philox word already drawn
+__device__ __forceinline__ float noise_denominator_w(int noise_mode, const float* noise, size_t local_idx, uint32_t word,
+                                                     bool multinomial) {
+  if (noise_mode == SGPO_NOISE_NONE) return 1.0f;
+  if (noise_mode == SGPO_NOISE_EXPONENTIAL) return noise[local_idx];
+  float u;
+  if (noise_mode == SGPO_NOISE_UNIFORM) {
+    u = noise[local_idx];
+    if (multinomial) return -logf(1.0f - u);
+    return 1e-10f - logf(u + 1e-10f);
+  }
+  u = u01_open(word);
+  if (multinomial) return -logf(u);
+  return 1e-10f - logf(u + 1e-10f);
+}
+
+// Half-wave (32-lane) all-reduces for the MDLM kernel: four DPP steps (lane^1, lane^2, mirror inside 8, mirror inside 16:
+// one VALU instruction each, no LDS crossbar) and one swizzle across the two rows of 16, instead of five ds_bpermute.
+#define SGPO_DPP_F(v, ctrl) __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), (ctrl), 0xF, 0xF, true))
+#define SGPO_SWZ16_F(v) __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x401F))   // lane ^ 16 within 32
+__device__ __forceinline__ float hsum32(float v) {
+  v += SGPO_DPP_F(v, 0xB1);
+  v += SGPO_DPP_F(v, 0x4E);
+  v += SGPO_DPP_F(v, 0x141);
+  v += SGPO_DPP_F(v, 0x140);
+  return v + SGPO_SWZ16_F(v);
+}
+__device__ __forceinline__ float hmax32(float v) {
+  v = fmaxf(v, SGPO_DPP_F(v, 0xB1));
+  v = fmaxf(v, SGPO_DPP_F(v, 0x4E));
+  v = fmaxf(v, SGPO_DPP_F(v, 0x141));
+  v = fmaxf(v, SGPO_DPP_F(v, 0x140));
+  return fmaxf(v, SGPO_SWZ16_F(v));
+}
+// lowest lane of the half holding the maximum (torch.argmax on CPU); no lane matches (every value NaN) -> 0, which is
+// what the exchange loop of half_argmax leaves in lane 0
+__device__ __forceinline__ int hargmax32(float v) {
+  const float m = hmax32(v);
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(v == m);
+  const unsigned hm = (unsigned)(bal >> (threadIdx.x & 32));
+  return hm ? __ffs(hm) - 1 : 0;
+}
+
 __device__ __forceinline__ float noise_denominator(int noise_mode, const float* noise, size_t local_idx,
                                                    uint64_t seed, uint64_t offset, uint64_t global_idx, bool multinomial) {
   // returns the value each probability is divided by before the argmax
@@ -44,23 +87,16 @@ __device__ __forceinline__ float noise_denominator(int noise_mode, const float* 
   return 1e-10f - logf(u + 1e-10f);
 }
 
-__global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
-    const float* __restrict__ logits, const int64_t* __restrict__ x, const float* __restrict__ log_ratio,
-    const int* __restrict__ slot_of_pos, int n_slots, int rows, int L, int K, int mask_index, float mt, float ms,
-    float guide_temp, int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed,
-    uint64_t offset, uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out,
-    int* __restrict__ nan_flag) {
-  const int half = (blockIdx.x * 256 + threadIdx.x) >> 5;  // row index
-  const int k = threadIdx.x & 31;
-  if (half >= rows) return;
-  const int row = half;
-  const bool act = k < K;
-  const int xt = (int)x[row];
-  float z = act ? logits[(size_t)row * K + k] : -INFINITY;
+// One row of the step, its inputs already in registers (z: the logit of class k or -inf; lr: the jump log-ratio of
+// class k, used when has_lr).  Called with all 32 lanes of the half-wave.
+__device__ __forceinline__ void reverse_step_mdlm_row(
+    int row, int k, bool act, int xt, float z, bool guided, bool has_lr, float lr, int K, int mask_index, float mt, float ms,
+    float guide_temp, int step_mode, int noise_mode, const float* __restrict__ noise, uint32_t philox_word,
+    int64_t* __restrict__ x_out, float* __restrict__ probs_out, int* __restrict__ nan_flag) {
   // subs parameterisation
   if (k == mask_index) z += NEG_INF_REF;
-  const float zmax = half_max(z);
-  const float se = half_sum(act ? expf(z - zmax) : 0.f);
+  const float zmax = hmax32(z);
+  const float se = hsum32(act ? expf(z - zmax) : 0.f);
   float lp = z - (zmax + logf(se));  // logits - logsumexp
   if (xt != mask_index) lp = (k == xt) ? 0.f : NEG_INF_REF;
   float q = expf(lp) * (mt - ms);
@@ -72,40 +108,95 @@ __global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
     return;
   }
   const size_t lidx = (size_t)row * K + k;
-  const uint64_t gidx = ((uint64_t)row + row_offset) * (uint64_t)K + k;
   if (step_mode == SGPO_STEP_HARD) {
     // _sample_categorical + carry-over (models/mdlm.py:81-84)
-    float den = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, false) : 1.f;
+    float den = act ? noise_denominator_w(noise_mode, noise, lidx, philox_word, false) : 1.f;
     float v = act ? q / den : -INFINITY;
-    int samp = half_argmax(v, k);
+    int samp = hargmax32(v);
     if (probs_out && act) probs_out[lidx] = q;
     if (k == 0) x_out[row] = (xt != mask_index) ? xt : samp;
     return;
   }
   // classifier guidance (cls_guidance.py:38-52)
   if (k == xt) q -= 1.0f;
-  if (log_ratio != nullptr && guide_temp != 0.f) {
-    const int l = row % L;
-    const int slot = slot_of_pos ? slot_of_pos[l] : l;
-    if (slot >= 0 && act) {
-      const int b = row / L;
-      float lr = log_ratio[((size_t)b * n_slots + slot) * K + k];
-      lr = lr / guide_temp;
-      if (lr == lr) lr = fminf(lr, 80.0f);  // torch.clamp propagates NaN, fminf would drop it
-      q = q * expf(lr);
-    }
-    if (nan_flag && act && q != q) *nan_flag = 1;
+  if (has_lr) {
+    lr = lr / guide_temp;
+    if (lr == lr) lr = fminf(lr, 80.0f);  // torch.clamp propagates NaN, fminf would drop it
+    q = q * expf(lr);
   }
+  if (guided && nan_flag && act && q != q) *nan_flag = 1;
   if (k == xt) q += 1.0f;
   q = fmaxf(q, 0.f);
   if (!act) q = 0.f;
-  const float tot = half_sum(q);
+  const float tot = hsum32(q);
   const float p = q / tot;
-  float den = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, true) : 1.f;
+  float den = act ? noise_denominator_w(noise_mode, noise, lidx, philox_word, true) : 1.f;
   float v = act ? p / den : -INFINITY;
-  int samp = half_argmax(v, k);
+  int samp = hargmax32(v);
   if (probs_out && act) probs_out[lidx] = p;
   if (k == 0) x_out[row] = samp;
+}
+
+// A half-wave takes RS_ROWS consecutive rows and requests all their inputs before the first row is worked on: with
+// one 124-byte row per half-wave the kernel had ~0.5 KB in flight per wave and was bound by memory latency
+// (1 TB/s with every wave slot of the chip occupied).
+#define RS_ROWS 4
+__global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
+    const float* __restrict__ logits, const int64_t* __restrict__ x, const float* __restrict__ log_ratio,
+    const int* __restrict__ slot_of_pos, int n_slots, int rows, int L, int K, int mask_index, float mt, float ms,
+    float guide_temp, int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed,
+    uint64_t offset, uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out,
+    int* __restrict__ nan_flag) {
+  const int half = (blockIdx.x * 256 + threadIdx.x) >> 5;
+  const int k = threadIdx.x & 31;
+  const int row0 = half * RS_ROWS;
+  if (row0 >= rows) return;
+  const bool act = k < K;
+  const bool guided = step_mode == SGPO_STEP_SOFT_CG && log_ratio != nullptr && guide_temp != 0.f;
+  int xt[RS_ROWS];
+  float z[RS_ROWS], lr[RS_ROWS];
+  bool has_lr[RS_ROWS];
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    const int row = row0 + r;
+    const bool valid = row < rows;          // uniform over the half-wave
+    xt[r] = valid ? (int)x[row] : mask_index;
+    z[r] = (valid && act) ? logits[(size_t)row * K + k] : -INFINITY;
+    lr[r] = 0.f;
+    has_lr[r] = false;
+    if (guided && valid && act) {
+      const int l = row % L;
+      const int slot = slot_of_pos ? slot_of_pos[l] : l;
+      if (slot >= 0) {
+        lr[r] = log_ratio[((size_t)(row / L) * n_slots + slot) * K + k];
+        has_lr[r] = true;
+      }
+    }
+  }
+  // In-kernel noise: one Philox4x32-10 call serves class k of FOUR consecutive global rows (counter = (global row >> 2)
+  // * K + k, word = global row & 3), so a call is shared by the rows of this half-wave instead of one word of four
+  // being used.  Keyed by the global row, so any sharding draws the same numbers; a group that straddles two
+  // counters (first global row no multiple of 4) makes a second call.
+  uint32_t pw[RS_ROWS] = {0, 0, 0, 0};
+  if (noise_mode == SGPO_NOISE_PHILOX && step_mode != SGPO_STEP_SOFT) {
+    const uint64_t g0 = (uint64_t)row0 + row_offset;
+    const Philox4 a = philox4x32_10(seed, (g0 >> 2) * (uint64_t)K + k, offset);
+    Philox4 b = a;
+    if (g0 & 3) b = philox4x32_10(seed, ((g0 >> 2) + 1) * (uint64_t)K + k, offset);
+#pragma unroll
+    for (int r = 0; r < RS_ROWS; ++r) {
+      const uint64_t g = g0 + r;
+      const Philox4& c = ((g >> 2) == (g0 >> 2)) ? a : b;
+      const int wsel = (int)(g & 3);
+      pw[r] = wsel == 0 ? c.x : wsel == 1 ? c.y : wsel == 2 ? c.z : c.w;
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < RS_ROWS; ++r) {
+    if (row0 + r < rows)
+      reverse_step_mdlm_row(row0 + r, k, act, xt[r], z[r], guided, has_lr[r], lr[r], K, mask_index, mt, ms, guide_temp, step_mode,
+                            noise_mode, noise, pw[r], x_out, probs_out, nan_flag);
+  }
 }
 
 extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* log_ratio,
@@ -124,7 +215,7 @@ extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, con
   SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise_mode == SGPO_NOISE_NONE || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_mdlm: noise tensor missing");
   SGPO_REQUIRE(log_ratio == nullptr || slot_of_pos != nullptr || n_slots == L, "reverse_step_mdlm: n_slots must equal L without a slot map");
   const int rows = B * L;
-  const int blocks = (rows + 7) / 8;
+  const int blocks = ((rows + RS_ROWS - 1) / RS_ROWS + 7) / 8;   // 8 half-waves per block, RS_ROWS rows each
   // algorithmic bytes: logits + x in, x out (+ ratio for guided steps)
   ProfScope prof_scope(PK_REVERSE_STEP, (hipStream_t)stream,
                        (double)rows * (K * 4.0 * ((log_ratio && guide_temp != 0.f && step_mode == SGPO_STEP_SOFT_CG) ? 2 : 1) + 16.0));
