@@ -12,19 +12,32 @@
 #include "common.h"
 #include "prof.h"
 
-__device__ __forceinline__ int half_argmax_d(double v, int k) {
-#pragma unroll
-  for (int o = 16; o > 0; o >>= 1) {
-    double ov = __shfl_xor(v, o);
-    int ok = __shfl_xor(k, o);
-    if (ov > v || (ov == v && ok < k)) { v = ov; k = ok; }
+// fp64 half-wave (32-lane) all-reduces: four DPP steps on the two words of the double (lane^1, lane^2, mirror inside 8,
+// mirror inside 16) and one swizzle across the two rows of 16 -- no ds_bpermute (two per exchanged double before).
+#define D3_DPP_I(v, ctrl) __builtin_amdgcn_update_dpp(0, (v), (ctrl), 0xF, 0xF, true)
+__device__ __forceinline__ double d3_dpp(double v, int step) {
+  const int lo = __double2loint(v), hi = __double2hiint(v);
+  switch (step) {
+    case 0: return __hiloint2double(D3_DPP_I(hi, 0xB1), D3_DPP_I(lo, 0xB1));
+    case 1: return __hiloint2double(D3_DPP_I(hi, 0x4E), D3_DPP_I(lo, 0x4E));
+    case 2: return __hiloint2double(D3_DPP_I(hi, 0x141), D3_DPP_I(lo, 0x141));
+    case 3: return __hiloint2double(D3_DPP_I(hi, 0x140), D3_DPP_I(lo, 0x140));
+    default: return __hiloint2double(__builtin_amdgcn_ds_swizzle(hi, 0x401F), __builtin_amdgcn_ds_swizzle(lo, 0x401F));
   }
-  return k;
 }
 __device__ __forceinline__ double half_sum_d(double v) {
 #pragma unroll
-  for (int o = 16; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  for (int st = 0; st < 5; ++st) v += d3_dpp(v, st);
   return v;
+}
+// lowest lane of the half holding the maximum (torch.argmax on CPU; inactive lanes carry -1)
+__device__ __forceinline__ int half_argmax_d(double v, int k) {
+  double m = v;
+#pragma unroll
+  for (int st = 0; st < 5; ++st) m = fmax(m, d3_dpp(m, st));
+  const unsigned long long bal = __builtin_amdgcn_ballot_w64(v == m);
+  const unsigned hm = (unsigned)(bal >> (threadIdx.x & 32));
+  return hm ? __ffs(hm) - 1 : 0;
 }
 
 __global__ __launch_bounds__(256) void d3pm_posterior_kernel(
@@ -34,15 +47,17 @@ __global__ __launch_bounds__(256) void d3pm_posterior_kernel(
     int64_t* __restrict__ x_out, double* __restrict__ probs_out) {
   __shared__ double qb[32 * 32];
   __shared__ float dq[32 * 32];
+  __shared__ double p0s[8][32];   // per half-wave: the row's p0, read back as broadcasts (was two ds_bpermute per term)
   for (int i = threadIdx.x; i < S * S; i += 256) {
     qb[(i / S) * 32 + (i % S)] = (double)q_bar[i];
     dq[(i / S) * 32 + (i % S)] = delta_q[i];
   }
   __syncthreads();
-  const int row = (blockIdx.x * 256 + threadIdx.x) >> 5;
   const int j = threadIdx.x & 31;
-  if (row >= rows) return;
   const bool act = j < S;
+  // a workgroup walks many rows: staging the two S x S matrices (1352 loads + conversions) once per 8 rows was most of
+  // the kernel's time
+  for (int row = (blockIdx.x * 256 + threadIdx.x) >> 5; row < rows; row += gridDim.x * 8) {
   int xt = (int)x[row];
   xt = xt < 0 ? 0 : (xt >= S ? S - 1 : xt);
   // fp32 softmax over the first S logits (F.softmax(model(x,t)[:,:,:S]), models/d3pm.py:37)
@@ -53,9 +68,13 @@ __global__ __launch_bounds__(256) void d3pm_posterior_kernel(
   const double p0 = (double)p0f;
   const double A = act ? (double)dq[j * 32 + xt] : 0.0;  // Delta_Q.T[x][j]
   double acc = 0.0;
-  const int hbase = threadIdx.x & 32;
+  double* ph = p0s[threadIdx.x >> 5];
+  ph[j] = p0;                                   // written and read by the same wave: LDS keeps program order
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   for (int i = 0; i < S; ++i) {
-    const double pi = __shfl(p0, hbase + i);
+    const double pi = ph[i];
     const double b = pi * qb[i * 32 + (act ? j : 0)];
     acc += (A * b) * pi;
   }
@@ -63,7 +82,7 @@ __global__ __launch_bounds__(256) void d3pm_posterior_kernel(
   const double p = acc / half_sum_d(acc);
   const size_t lidx = (size_t)row * S + j;
   if (probs_out && act) probs_out[lidx] = p;
-  if (step_mode == SGPO_STEP_SOFT) return;
+  if (step_mode == SGPO_STEP_SOFT) continue;
   double den = 1.0;
   if (act) {
     if (noise_mode == SGPO_NOISE_EXPONENTIAL) den = reinterpret_cast<const double*>(noise)[lidx];
@@ -74,6 +93,7 @@ __global__ __launch_bounds__(256) void d3pm_posterior_kernel(
   }
   const int samp = half_argmax_d(act ? p / den : -1.0, j);
   if (j == 0) x_out[row] = samp;
+  }
 }
 
 extern "C" int sgpo_reverse_step_d3pm(const float* logits, int ld_logits, const int64_t* x, int N, int L, int S,
@@ -90,7 +110,9 @@ extern "C" int sgpo_reverse_step_d3pm(const float* logits, int ld_logits, const 
   const int rows = N * L;
   hipStream_t st = (hipStream_t)stream;
   ProfScope prof_scope(PK_D3PM_POSTERIOR, st, (double)rows * (ld_logits * 4.0 + 16.0));
-  hipLaunchKernelGGL(d3pm_posterior_kernel, dim3((rows + 7) / 8), dim3(256), 0, st, logits, ld_logits, x, rows, S, delta_q,
+  int blocks = (rows + 7) / 8;
+  if (blocks > 4096) blocks = 4096;   // 16 workgroups per CU; each walks rows with a grid stride
+  hipLaunchKernelGGL(d3pm_posterior_kernel, dim3(blocks), dim3(256), 0, st, logits, ld_logits, x, rows, S, delta_q,
                      q_bar, step_mode, noise_mode, noise, seed, offset, row_offset, x_out, probs_out);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
