@@ -19,9 +19,10 @@
  *   - return 0 on success, negative on error; sgpo_last_error() gives the text.
  *     Nothing throws across the ABI.
  *   - noise: noise_mode 0 = in-kernel Philox4x32-10 keyed by (seed, call offset,
- *     GLOBAL element index) so results are invariant to how a batch is sharded
- *     over ranks (row_offset = first global row of this shard); noise_mode 1/2 =
- *     the caller passes the noise tensor (parity runs).
+ *     GLOBAL element index; in sgpo_reverse_step_mdlm: GLOBAL row / 4 and class,
+ *     word = row % 4) so results are invariant to how a batch is sharded over
+ *     ranks (row_offset = first global row of this shard); noise_mode 1/2 = the
+ *     caller passes the noise tensor (parity runs).
  */
 #ifndef SGPO_HIP_H
 #define SGPO_HIP_H
