@@ -113,21 +113,19 @@ def bytenet_synthetic_state(seed=0, n_tokens=31, d_embedding=8, d_model=1024, n_
 def load_lightning_state(path, prefix):
     """Read `state_dict` from a Lightning .ckpt (local file only) and strip `prefix`.
 
-    Checkpoint/resume hook of SURVEY.md §5: `.ckpt -> flat weight dict`.  Uses the non-executing
-    loader (`weights_only=True`).  Lightning checkpoints that carry pickled hyper-parameter objects are refused
-    by it; the full unpickler runs arbitrary code from the file, so it is used only when the caller opts in
-    for a file they trust with SGPO_TRUST_CHECKPOINT=1.
+    Checkpoint/resume hook of SURVEY.md §5: `.ckpt -> flat weight dict`.  Only the non-executing loader
+    (`weights_only=True`) is ever used: a full unpickle runs code from the file, and there is no switch that
+    turns it on.  A Lightning checkpoint that carries pickled hyper-parameter objects is refused; re-save its
+    tensors (`torch.save({'state_dict': ckpt['state_dict']}, path)`) on a machine where the file is trusted.
     """
     if not os.path.exists(path):
         raise FileNotFoundError(path)
     try:
         ck = torch.load(path, map_location='cpu', weights_only=True)
     except Exception as e:
-        if os.environ.get('SGPO_TRUST_CHECKPOINT') != '1':
-            raise RuntimeError(f'{path}: the non-executing loader refused this checkpoint ({type(e).__name__}: {e}). '
-                               f'Re-save its state_dict with torch.save, or set SGPO_TRUST_CHECKPOINT=1 to unpickle a '
-                               f'file you trust.') from e
-        ck = torch.load(path, map_location='cpu', weights_only=False)
+        raise RuntimeError(f'{path}: the non-executing loader refused this checkpoint ({type(e).__name__}: {e}). '
+                           f"Re-save its tensors with torch.save({{'state_dict': ckpt['state_dict']}}, path); "
+                           f'this library never unpickles a checkpoint.') from e
     sd = ck['state_dict'] if 'state_dict' in ck else ck
     out = {}
     for k, v in sd.items():

@@ -70,9 +70,10 @@ def test_checkpoint_importer_uses_the_non_executing_loader(tmp_path, monkeypatch
     sd = W.load_lightning_state(p, 'backbone.')
     assert list(sd) == ['blocks.0.w'] and sd['blocks.0.w'].dtype == torch.float32
     torch.save({'state_dict': {'backbone.w': torch.ones(3)}, 'hyper_parameters': _Hyper()}, p)
-    monkeypatch.delenv('SGPO_TRUST_CHECKPOINT', raising=False)
+    monkeypatch.setenv('SGPO_TRUST_CHECKPOINT', '1')        # the former opt-in: no environment switch unpickles any more
     with pytest.raises(RuntimeError, match='non-executing loader refused'):
         W.load_lightning_state(p, 'backbone.')
+    assert 'weights_only=False' not in inspect.getsource(W)
     with pytest.raises(KeyError):
         torch.save({'state_dict': {'other.w': torch.ones(3)}}, p)
         W.load_lightning_state(p, 'backbone.')
