@@ -141,6 +141,19 @@ int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L
  * and the mask column everywhere, are bit-identical to sgpo_guidance_ratio_mlp).  Same workspace. */
 int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index,
                                       float* log_ratio, void* workspace, size_t workspace_bytes, void* stream);
+/* sgpo_guidance_ratio_mlp_absorbing for callers that cannot allocate.  No counterpart in the reference: it is for
+ * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc, which have no way to
+ * provide the workspace.  Same arguments minus the workspace, same kernels, same bits in log_ratio.  The
+ * workspace (sgpo_mlp_workspace_bytes(m, B) bytes) is a device array inside the library, at most
+ * SGPO_GUIDANCE_NOALLOC_MAX_BYTES per GPU: a call that needs more (e.g. more than about 5 600 sequences with 119 read positions)
+ * returns an error naming the sizes.  The call allocates nothing (no hipMalloc/hipFree, no host allocation with
+ * per-kernel timing off).  Every call on a GPU shares that GPU's array: calls that overlap on one GPU
+ * (different streams or threads) race; calls on one stream are ordered.  Nothing in the array has to start at
+ * zero -- each call writes every word it later reads. */
+#define SGPO_GUIDANCE_NOALLOC_MAX_BYTES (4u << 20)
+size_t sgpo_guidance_noalloc_max_bytes(void);
+int sgpo_guidance_ratio_mlp_absorbing_noalloc(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S,
+                                              int mask_index, float* log_ratio, void* stream);
 
 /* ---- fitness-oracle ensemble: oracle/inference_oracle.py:19-72 ---------
  * OracleModel (oracle/train_oracle.py:61-74) = Linear(20*n_res, hidden) -> ReLU -> Linear(hidden, 1) on the

@@ -20,13 +20,15 @@ extern "C" void sgpo_set_error(const char* fmt, ...) {
 extern "C" const char* sgpo_last_error(void) { return g_err; }
 extern "C" int sgpo_version(void) { return 1; }
 extern "C" int sgpo_gemm_init_device();
+extern "C" int sgpo_guidance_init_device();
 
 extern "C" int sgpo_init(int device) {
   int n = 0;
   SGPO_CHECK_HIP(hipGetDeviceCount(&n));
   SGPO_REQUIRE(device >= 0 && device < n, "sgpo_init: device %d not in [0,%d)", device, n);
   SGPO_CHECK_HIP(hipSetDevice(device));
-  return sgpo_gemm_init_device();
+  if (int rc = sgpo_gemm_init_device()) return rc;
+  return sgpo_guidance_init_device();   // device address of the allocation-free entry point's scratch array
 }
 
 // ------------------------------------------------------------------ small kernels

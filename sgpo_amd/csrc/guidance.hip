@@ -11,6 +11,7 @@
 // the exact-fp32 MFMA (v_mfma_f32_32x32x2_f32: bit-for-bit an fp32 fma chain), one 32-lane
 // tile = the 31(+1) jumps of one (sequence, read position), "transposed" so that the
 // activation accumulator of one layer is the B operand of the next with no data movement.
+#include <mutex>
 #include <vector>
 
 #include "../../include/sgpo_hip.h"
@@ -427,4 +428,56 @@ extern "C" int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, 
                                                  float* log_ratio, void* workspace, size_t workspace_bytes, void* stream) {
   SGPO_REQUIRE(mask_index >= 0, "guidance_ratio_mlp_absorbing: mask_index %d", mask_index);
   return guidance_ratio(m, x, t, B, L, S, mask_index, log_ratio, workspace, workspace_bytes, stream);
+}
+
+// ---- the same call for callers that cannot allocate -----------------------------------------
+// The workspace of guidance_ratio (hpre | cnt | lists) lives in a device array that is part of the code
+// object: every GPU the library runs on holds its own copy, at its own address, until the process ends.
+// `scratch` is only the host-side name of that array; the device address is asked for once per device
+// (sgpo_guidance_init_device, called by sgpo_init, or the first call on a device) and host code uses that
+// pointer from then on.
+static __device__ __align__(256) unsigned char scratch[SGPO_GUIDANCE_NOALLOC_MAX_BYTES];
+#define SGPO_MAX_DEVICES 16
+static void* g_scratch_ptr[SGPO_MAX_DEVICES] = {nullptr};
+static std::mutex g_scratch_mutex;
+
+static int scratch_of_current_device(void** out) {
+  int dev = -1;
+  SGPO_CHECK_HIP(hipGetDevice(&dev));
+  SGPO_REQUIRE(dev >= 0 && dev < SGPO_MAX_DEVICES, "guidance scratch: device index %d outside [0,%d)", dev, SGPO_MAX_DEVICES);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    void* p = nullptr;
+    SGPO_CHECK_HIP(hipGetSymbolAddress((void**)&p, HIP_SYMBOL(scratch)));
+    SGPO_REQUIRE(p != nullptr, "guidance scratch: hipGetSymbolAddress returned a null address on device %d", dev);
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return SGPO_OK;
+}
+
+extern "C" int sgpo_guidance_init_device() {  // called from sgpo_init with the rank's device current
+  void* p = nullptr;
+  return scratch_of_current_device(&p);
+}
+
+extern "C" size_t sgpo_guidance_noalloc_max_bytes(void) { return SGPO_GUIDANCE_NOALLOC_MAX_BYTES; }
+
+extern "C" int sgpo_guidance_ratio_mlp_absorbing_noalloc(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S,
+                                                         int mask_index, float* log_ratio, void* stream) {
+  SGPO_REQUIRE(m && x && log_ratio, "guidance_ratio_mlp_absorbing_noalloc: null argument");
+  SGPO_REQUIRE(mask_index >= 0, "guidance_ratio_mlp_absorbing_noalloc: mask_index %d", mask_index);
+  SGPO_REQUIRE(B > 0, "guidance_ratio_mlp_absorbing_noalloc: B=%d", B);
+  const size_t need = sgpo_mlp_workspace_bytes(m, B);
+  if (need > SGPO_GUIDANCE_NOALLOC_MAX_BYTES) {
+    sgpo_set_error("guidance_ratio_mlp_absorbing_noalloc: B=%d with %d read positions needs %zu bytes of scratch, the built-in "
+                   "buffer holds %zu; use sgpo_guidance_ratio_mlp_absorbing with a caller workspace", B, m->n_read, need,
+                   (size_t)SGPO_GUIDANCE_NOALLOC_MAX_BYTES);
+    return SGPO_ERR_WORKSPACE;
+  }
+  void* ws = nullptr;
+  if (int rc = scratch_of_current_device(&ws)) return rc;
+  // nothing in the buffer has to start at zero: mlp_base_kernel writes hpre, cnt and lists of every row b < B before
+  // mlp_jump_kernel (same stream) reads them, and no row >= B is read
+  return guidance_ratio(m, x, t, B, L, S, mask_index, log_ratio, ws, need, stream);
 }

@@ -40,6 +40,7 @@ extern "C" int sgpo_prof_enable(int on, int max_launches) {
       g_pool.push_back(e);
     }
     g_next = 0; g_recs.clear();
+    g_recs.reserve(want / 2);   // no host allocation while recording either
   }
   g_on = on != 0;
   return SGPO_OK;
