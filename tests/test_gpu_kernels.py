@@ -65,7 +65,7 @@ def test_dit_forward(rt, name):
     # (a) against the reference's fp32 CPU logits (golden): bf16 tolerance
     scale = g['logits'].abs().max()
     err = (logits - g['logits']).abs().max() / scale
-    assert err < 2e-2, f'max err / max |logit| = {err:.3e}'
+    assert err < 1e-2, f'max err / max |logit| = {err:.3e}'      # north_star: bf16 rtol 1e-2
     torch.testing.assert_close(hidden, g['h_last'], rtol=5e-2, atol=5e-2 * float(g['h_last'].abs().max()))
     # (b) the device error must be of the size the bf16 autocast rounding itself produces:
     #     compare with the oracle rounding to bf16 at the points torch autocast does (defect D7)
@@ -74,7 +74,7 @@ def test_dit_forward(rt, name):
     err16 = (logits - ref16).abs().max() / scale
     print(f'{name}: dev-vs-fp32 {err:.3e}  bf16emu-vs-fp32 {err_emu:.3e}  dev-vs-bf16emu {err16:.3e}')
     assert err < 2.0 * err_emu + 2e-3
-    assert err16 < 1.5e-2
+    assert err16 < 1e-2
     # x_emb bypass (dit.py:397-410)
     l2 = net.forward(x, sigma, x_emb=(g['h_last'] * 0.5 + 0.1).cuda()).cpu()
     err2 = (l2 - g['logits_xemb']).abs().max() / g['logits_xemb'].abs().max()

@@ -44,12 +44,27 @@ def test_nos_denoise_against_reference(env, name):
         net.injected_noise.append(u)
         xs, probs, _ = net._nos_denoise(head, int(nsteps), lr, coef, g['x'].cuda(), torch.tensor(int(t)))
         p_ref = g[f'probs_{tag}']
-        # the backbone is bf16 on the device: hidden-state error propagates to the probabilities
-        torch.testing.assert_close(probs.cpu(), p_ref, rtol=5e-2, atol=2e-3)
+        # Tolerance (north_star: guided logits within bf16 rtol 1e-2): the probabilities are a softmax of the final
+        # layer on h + delta, so a relative error of p is an absolute error of a guided logit; it is bounded by
+        # 1e-2 of the largest guided logit of the oracle (delta grows by up to nos_step_size per coordinate and
+        # step, so these logits are several times the denoiser's own: the scale is printed).
+        from oracle import dit as odit
+        from sgpo_amd import runtime as rt
+        _, _, d_ref = onos.nos_denoise(sd, g['w_cls'], g['b_cls'], g['x'], int(t), T, 28, int(nsteps), lr, coef, u)
+        _, hs = odit.dit_forward(sd, g['x'], torch.zeros(B), return_hidden_states=True)
+        z_g = odit.dit_forward(sd, g['x'], torch.zeros(B), x_emb=hs[-1] + d_ref)
+        scale_z = float(z_g[g['x'] == 28].abs().max())
+        rtol_p, atol_p = 1e-2 * scale_z, 2e-6
+        dp = (probs.cpu() - p_ref).abs()
+        big = p_ref > 1e-3
+        print(f'[nos {name} {tag}] max |guided logit| {scale_z:.2f} -> rtol_p {rtol_p:.3f}; worst relative error of p where '
+              f'p > 1e-3: {float((dp[big] / p_ref[big]).max()):.2e}; worst |dp| / tolerance: '
+              f'{float((dp / (atol_p + rtol_p * p_ref)).max()):.3f}')
+        torch.testing.assert_close(probs.cpu(), p_ref, rtol=rtol_p, atol=atol_p)
         # tokens must agree wherever the race p / E cannot flip inside that tolerance: the reference winner's lower
         # bound beats every other entry's upper bound (unmasked positions carry over whatever the probabilities)
         E = 1e-10 - (u + 1e-10).log()
-        lo, hi = (p_ref * (1 - 5e-2) - 2e-3).clamp_min(0) / E, (p_ref * (1 + 5e-2) + 2e-3) / E
+        lo, hi = (p_ref * (1 - rtol_p) - atol_p).clamp_min(0) / E, (p_ref * (1 + rtol_p) + atol_p) / E
         win = (p_ref / E).argmax(-1, keepdim=True)
         ok = (lo.gather(-1, win) > hi.scatter(-1, win, 0.).max(-1, keepdim=True).values).squeeze(-1) | (g['x'] != 28)
         print(f'{name} {tag}: {float(ok.float().mean()):.3f} of the positions are decided beyond the tolerance')
@@ -58,10 +73,6 @@ def test_nos_denoise_against_reference(env, name):
         assert torch.equal(xs.cpu()[g['x'] != 28], g['x'][g['x'] != 28])      # carry-over
         # the optimised delta itself against the autograd oracle, fed the oracle's fp32 hidden state so
         # that only the closed-form backward + Adagrad are compared (fp32 both sides)
-        from oracle import dit as odit
-        from sgpo_amd import runtime as rt
-        _, _, d_ref = onos.nos_denoise(sd, g['w_cls'], g['b_cls'], g['x'], int(t), T, 28, int(nsteps), lr, coef, u)
-        _, hs = odit.dit_forward(sd, g['x'], torch.zeros(B), return_hidden_states=True)
         mt, ms, _ = net._move_chances(int(t))
         xs2, p2, d = rt.nos_denoise(net.net, g['x'].cuda(), g['w_cls'], int(nsteps), lr, coef, mt, ms, 28,
                                     want_delta=True, noise=u, hidden_in=hs[-1])

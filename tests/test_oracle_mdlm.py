@@ -110,3 +110,47 @@ def test_cls_guidance_inference_full_size():
     x = ocg.inference_mdlm(sd, B, L, int(g['T']), 28, golden_noise(g, B, L), predictor=pred, temperature=float(g['temp']))
     assert torch.equal(x, g['x'])
     torch.testing.assert_close(pred.log_likelihood(x), g['fitness'], rtol=1e-5, atol=1e-6)
+
+
+ALPHABET = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+
+
+def test_cls_guidance_inference_trpb_residue_subset():
+    """The residue-subset form every TrpB run uses (real DiT dims, L = 389, the 15 residues of configs/data/TrpB.yaml
+    read raw by the value function -- defect D3 --, temperature 0.064, B = 2, T = 16): the restatement visits the
+    reference's states one by one and its projected result equals the reference's."""
+    g = load_golden('cg_real_guided_trpb')
+    sd = _sd(g)
+    B, L = g['x'].shape
+    T = int(g['T'])
+    res = [int(r) for r in g['residues']]
+    pred = omlp.Predictor(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res)), res)
+    x, trace = ocg.inference_mdlm(sd, B, L, T, 28, golden_noise(g, B, L), predictor=pred, temperature=float(g['temp']),
+                                  return_trace=True)
+    states = g['states'].long()
+    assert torch.equal(states[0], torch.full((B, L), 28))
+    for i in range(1, T - 1):
+        assert torch.equal(trace[i - 1], states[i]), f'state before step {i}'
+    full = torch.tensor([ALPHABET.index(c) for c in bytes(g['full_seq'].numpy().tolist()).decode()])
+    mask = torch.zeros(L, dtype=torch.int64)
+    mask[[r - 1 for r in res]] = 1                       # sampling/base.py:30: the mutated set is the 0-indexed list
+    assert torch.equal(ocg.project(x, mask, full), g['x'])
+    assert bool((x != g['x']).any())                     # the projection is not a no-op on this run
+
+
+def test_cls_guidance_config1_first_rows_teacher_forced():
+    """BASELINE config 1 (prior_sample.py:73: no forward_op, temperature 0; CreiLOV, real DiT dims, B = 64, 127 steps):
+    on the first four rows the restatement reproduces the reference's next state from each of its 127 states."""
+    g = load_golden('cg_real_unguided_b64')
+    sd = _sd(g)
+    B, L = g['x'].shape
+    T = int(g['T'])
+    states = g['states_first'].long()
+    n = states.shape[1]
+    es = golden_noise(g, B, L)[:, :n]
+    timesteps = torch.linspace(T - 1, 1, T - 1, dtype=int)
+    for i, t in enumerate(timesteps):
+        q = omdlm.p_sample(sd, states[i], t, T, 28, hard=False)
+        x_next, _ = ocg.cg_step(q, states[i], lambda qm: qm, es[i])
+        want = states[i + 1] if i + 1 < T - 1 else g['x'][:n]
+        assert torch.equal(x_next, want), f'step {i}'

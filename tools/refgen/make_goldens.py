@@ -250,6 +250,76 @@ def gen_cg_real():
          full_seq=np.frombuffer(CREILOV.encode(), dtype=np.uint8))
 
 
+def _record_states(net):
+    """Make the reference loop tell which state it hands to net.p_sample at every step (the reference's
+    inference returns the final tokens only)."""
+    states = []
+    orig = net.p_sample
+
+    def spy(x, t, *a, **k):
+        states.append(x.clone())
+        return orig(x, t, *a, **k)
+    net.p_sample = spy
+    return states
+
+
+def _yaml_value(path, key):
+    import yaml
+    with open(path) as f:
+        return yaml.safe_load(f)[key]
+
+
+def gen_cg_trpb():
+    """The residue-subset form of the guided step, as every TrpB run of MDLM + cls_guidance uses it: real DiT dims,
+    TrpB (L = 389, full_seq and the 15 residues of configs/data/TrpB.yaml; the value function reads the raw
+    1-indexed list, defect D3), temperature 0.064, B = 2, a short horizon (T = 16).  Stores the state before every
+    step and the projected result; the Exp(1) noise is redrawn from its seed by the test."""
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, T, temp, noise_seed = 2, 389, 16, 0.064, 78
+    full = _yaml_value(os.path.join(REF, 'configs', 'data', 'TrpB.yaml'), 'full_seq')
+    res = _yaml_value(os.path.join(REF, 'configs', 'data', 'TrpB.yaml'), 'residues')
+    assert res == TRPB_RES and len(full) == L
+    net, core, sd = build_ref_mdlm(REAL, seed=19, L=L, T=T)
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=full, residues=res))
+    pred, msd = build_ref_mlp(len(res), res, seed=37, full_len=L)
+    algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred, temperature=temp, device='cpu')
+    gen = torch.Generator().manual_seed(noise_seed)
+    es = torch.stack([torch.empty(B * L, 31).exponential_(1, generator=gen) for _ in range(T - 1)])
+    states = _record_states(net)
+    torch.manual_seed(noise_seed)
+    with torch.no_grad():
+        x = algo.inference(num_samples=B)
+    assert len(states) == T - 1
+    save('cg_real_guided_trpb', seed=19, mlp_seed=37, dims=np.array(list(REAL.values())), T=T, temp=temp,
+         noise_seed=noise_seed, es_isum=es.view(torch.int32).long().sum(), es_first=es[0, :4], x=x,
+         states=torch.stack(states).to(torch.int8), residues=np.array(res),
+         full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
+
+
+def gen_cg_cfg1():
+    """BASELINE config 1: the sampler prior_sample.py:73 builds (Classifier_Guidance_Inpaint with no forward_op, i.e.
+    temperature 0) on CreiLOV at the real DiT dims, B = 64, all 127 steps.  Stores the final tokens of all 64 rows and,
+    for the first four rows, the state before every step."""
+    import time
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, T, noise_seed, keep = 64, 119, 128, 79, 4
+    net, core, sd = build_ref_mdlm(REAL, seed=20, L=L, T=T)
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=CREILOV, residues=None))
+    algo = Classifier_Guidance_Inpaint(temperature=0., n_max_mutations=None, net=net, data_config=dc, device='cpu')
+    assert algo.temperature == 0. and algo.forward_op is None
+    gen = torch.Generator().manual_seed(noise_seed)
+    es = torch.stack([torch.empty(B * L, 31).exponential_(1, generator=gen) for _ in range(T - 1)])
+    states = _record_states(net)
+    torch.manual_seed(noise_seed)
+    t0 = time.time()
+    with torch.no_grad():
+        x = algo.inference(num_samples=B)
+    print(f'reference inference (config 1, B = {B}): {time.time() - t0:.1f} s')
+    save('cg_real_unguided_b64', seed=20, dims=np.array(list(REAL.values())), T=T, temp=0.0, noise_seed=noise_seed,
+         es_isum=es.view(torch.int32).long().sum(), es_first=es[0, :4], x=x, states_first=torch.stack(states)[:, :keep].to(torch.int8),
+         full_seq=np.frombuffer(CREILOV.encode(), dtype=np.uint8))
+
+
 BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
 
 
@@ -810,7 +880,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
