@@ -1,0 +1,5 @@
+"""Drop-in `problem`: the modules mirrored here win; any other `problem.*` falls through to the same-named directory
+of the reference code base when that is on sys.path (sgpo_amd/dropin/_fallthrough.py)."""
+from sgpo_amd.dropin._fallthrough import FallthroughPath
+
+__path__ = FallthroughPath(__path__, __name__)

@@ -107,3 +107,10 @@ class ProteinPredictor(nn.Module):
 
     def log_likelihood(self, inputs, y=None):
         return self(inputs, torch.zeros(inputs.shape[0], device=inputs.device)).squeeze(-1)
+
+
+# names of the reference module that are outside the sampling hot path -- Embedder, SampledDeterministicModel (training/train_GP_classifier.py:11,14) --
+# resolve to the reference's own definitions when its code base is on sys.path
+from sgpo_amd.dropin._fallthrough import forward_missing_names  # noqa: E402
+
+__getattr__ = forward_missing_names('problem', 'protein')

@@ -37,3 +37,10 @@ class NOS(Algo):
         if detokenize:
             return x, self.project_sequences(self._untokenize_batch(x))
         return x
+
+
+# names of the reference module that are outside the sampling hot path -- NOS_C (configs/algorithm/NOS_continuous.yaml) --
+# resolve to the reference's own definitions when its code base is on sys.path
+from sgpo_amd.dropin._fallthrough import forward_missing_names  # noqa: E402
+
+__getattr__ = forward_missing_names('sampling', 'NOS')

@@ -60,3 +60,10 @@ class Classifier_Guidance_Inpaint(Algo):
         src = getattr(self.net, 'noise_source', None)
         nz = self.net._next_noise() if hasattr(self.net, '_next_noise') else None
         return rt.categorical_sample(p, noise_src=src, noise=nz)
+
+
+# names of the reference module that are outside the sampling hot path -- Classifier_Guidance_Continuous (prior_sample.py:15, configs/algorithm/cls_guidance_continuous.yaml) --
+# resolve to the reference's own definitions when its code base is on sys.path
+from sgpo_amd.dropin._fallthrough import forward_missing_names  # noqa: E402
+
+__getattr__ = forward_missing_names('sampling', 'cls_guidance')

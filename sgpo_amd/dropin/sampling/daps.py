@@ -122,3 +122,10 @@ class DAPS(Algo):
         if detokenize:
             return xt, self.project_sequences(self._untokenize_batch(xt))
         return xt
+
+
+# names of the reference module that are outside the sampling hot path -- DAPS_continuous (configs/algorithm/daps_continuous.yaml) --
+# resolve to the reference's own definitions when its code base is on sys.path
+from sgpo_amd.dropin._fallthrough import forward_missing_names  # noqa: E402
+
+__getattr__ = forward_missing_names('sampling', 'daps')
