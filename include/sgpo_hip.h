@@ -91,7 +91,8 @@ int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float* sigma, int
  *   slot_of_pos: [L] slot index of each position or -1 (NULL = identity, n_slots = L);
  *   move_chance_t/s: scalars of models/mdlm.py:67-68 (host computes them, incl. defect D2);
  *   noise: [B][L][K] for noise_mode 1/2;  probs_out (optional) [B][L][K];
- *   nan_flag (optional): set to 1 if a guided rate is NaN (models/mdlm.py:410-411). */
+ *   nan_flag (optional, device int): bit 0 is set if a guided rate is NaN (models/mdlm.py:410-411), bit 1 if a
+ *   row of guided rates sums to 0, inf or NaN (torch.multinomial raises there, cls_guidance.py:52). */
 int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* log_ratio,
                            const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
                            float move_chance_t, float move_chance_s, float guide_temp, int step_mode,

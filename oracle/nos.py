@@ -15,14 +15,16 @@ NEG_INF = -1000000.0
 
 
 def nos_denoise(sd, w_cls, b_cls, xt, t, T, mask_index, num_nos_steps, nos_step_size, nos_stability_coef, u,
-                t_next_mode='reference'):
+                t_next_mode='reference', emulate_bf16=False):
+    """emulate_bf16: the backbone pass rounds to bf16 where torch autocast does (the reference's GPU arithmetic, defect
+    D7); the inner final-layer passes stay fp32.  Used to size the error a bf16 backbone alone puts into the result."""
     B = xt.shape[0]
     mt, ms, sig_t = omdlm.move_chances(t, T, B, t_next_mode)
     copy_flag = xt != mask_index
     sigma0 = torch.zeros_like(sig_t)                      # time_conditioning False (_process_sigma)
     with torch.no_grad():
-        logits, hs = odit.dit_forward(sd, xt, sigma0, return_hidden_states=True)
-        h = hs[-1]
+        logits, hs = odit.dit_forward(sd, xt, sigma0, return_hidden_states=True, emulate_bf16=emulate_bf16)
+        logits, h = logits.float(), hs[-1].float()
         log_x_theta = omdlm.subs_parameterization(logits, xt, mask_index)
         base = log_x_theta + torch.log(1. - (ms / mt))
         base[..., mask_index] = torch.log(ms / mt)[:, :, 0]

@@ -212,7 +212,8 @@ __global__ __launch_bounds__(1024) void acq_scan_kernel(int N, int n_needed, con
 // append the kept rows to the store and settle the slots this batch touched; one wave per batch row
 __global__ __launch_bounds__(256) void acq_commit_kernel(AcqDev d, const int64_t* __restrict__ tokens, int N, uint32_t n_store,
                                                          int n_needed, int round, const uint32_t* __restrict__ slot_of,
-                                                         const unsigned char* __restrict__ flag, const int* __restrict__ rank) {
+                                                         const unsigned char* __restrict__ flag, const int* __restrict__ rank,
+                                                         int* __restrict__ n_tomb) {
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   const int i = blockIdx.x * 4 + wave;
   if (i >= N) return;
@@ -233,11 +234,56 @@ __global__ __launch_bounds__(256) void acq_commit_kernel(AcqDev d, const int64_t
     if (rep >= n_store) {       // claimed by this batch
       d.slots[slot] = kept ? ((w & ~(uint64_t)ACQ_REP_MASK) | (uint64_t)(n_store + r)) : ACQ_TOMB;
       if (kept) d.slot_round[slot] = round;
+      else atomicAdd(n_tomb, 1);   // a claimed slot given up (row cut off by n_needed, or a batch that did not fit)
     } else if (kept) {
       d.slot_round[slot] = round;
     }
     d.first[slot] = ACQ_NONE;   // nobody reads `first` in this kernel
   }
+}
+
+// Tombstones are never claimed again by acq_insert_kernel (two rows with the same tokens could then settle on
+// different slots), so they only lengthen probe chains.  When they pile up the table is wiped and refilled from the
+// store: one wave per store row, same probing as acq_insert_kernel; rows with equal tokens (scope 0 keeps duplicates)
+// share the slot of whichever claimed it first, slot_round = the latest round among them.
+__global__ __launch_bounds__(256) void acq_rebuild_kernel(AcqDev d, uint32_t n_store, int* __restrict__ err) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const uint32_t i = blockIdx.x * 4 + wave;
+  if (i >= n_store) return;
+  const unsigned char* row = d.store + (size_t)i * d.L;
+  uint64_t h = 0;
+  for (int j = lane; j < d.L; j += 64) h += mix64((uint64_t)row[j] + ((uint64_t)(j + 1) << 32));   // == seq_hash
+  h = mix64(wave_sum_u64(h));
+  const uint64_t hi40 = h >> 24;
+  const uint64_t mine = (hi40 << 24) | (uint64_t)i;
+  uint32_t slot = (uint32_t)(h ^ (h >> 40)) & d.mask;
+  uint32_t probes = 0;
+  bool found = false;
+  while (!found) {
+    uint64_t cur = 0;
+    if (lane == 0) {
+      cur = __hip_atomic_load(&d.slots[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (cur == ACQ_EMPTY) {
+        uint64_t expect = ACQ_EMPTY;
+        cur = __hip_atomic_compare_exchange_strong(&d.slots[slot], &expect, mine, __ATOMIC_RELAXED, __ATOMIC_RELAXED,
+                                                   __HIP_MEMORY_SCOPE_AGENT) ? mine : expect;
+      }
+    }
+    cur = bcast_u64(cur);
+    if (cur == mine) { found = true; break; }
+    if ((cur >> 24) == hi40) {
+      const unsigned char* o = d.store + (size_t)((uint32_t)cur & ACQ_REP_MASK) * d.L;
+      bool eq = true;
+      for (int j = lane; j < d.L; j += 64) eq &= o[j] == row[j];
+      if (__all(eq)) { found = true; break; }
+    }
+    slot = (slot + 1) & d.mask;
+    if (++probes > d.mask) {
+      if (lane == 0) atomicOr(err, 1);
+      break;
+    }
+  }
+  if (found && lane == 0) atomicMax(&d.slot_round[slot], d.store_round[i]);
 }
 
 __global__ void acq_read_kernel(const unsigned char* __restrict__ store, size_t n, int64_t* __restrict__ out) {
@@ -274,7 +320,7 @@ struct sgpo_acq {
   uint32_t* slot_of;
   unsigned char* flag;
   int* rank;
-  int* counts;   // [0] appended, [1] admissible, [2] error bits
+  int* counts;   // [0] appended, [1] admissible, [2] error bits, [3] tombstones in the table
 };
 
 extern "C" int sgpo_project_tokens(int64_t* tokens, const int64_t* full_seq, int N, int L, int n_std, int n_special,
@@ -340,6 +386,25 @@ extern "C" void sgpo_acq_destroy(sgpo_acq* a) {
 
 extern "C" long long sgpo_acq_count(const sgpo_acq* a) { return a ? (long long)a->n_store : -1; }
 
+static int acq_rebuild(sgpo_acq* a, hipStream_t s) {
+  SGPO_CHECK_HIP(hipMemsetAsync(a->d.slots, 0xFF, a->table * 8, s));
+  SGPO_CHECK_HIP(hipMemsetAsync(a->d.first, 0xFF, a->table * 4, s));
+  SGPO_CHECK_HIP(hipMemsetAsync(a->d.slot_round, 0xFF, a->table * 4, s));
+  SGPO_CHECK_HIP(hipMemsetAsync(a->counts + 3, 0, 4, s));
+  if (a->n_store)
+    hipLaunchKernelGGL(acq_rebuild_kernel, dim3((a->n_store + 3) / 4), dim3(256), 0, s, a->d, a->n_store, a->counts + 2);
+  SGPO_CHECK_HIP(hipGetLastError());
+  int err = 0;
+  SGPO_CHECK_HIP(hipMemcpyAsync(&err, a->counts + 2, sizeof(int), hipMemcpyDeviceToHost, s));
+  SGPO_CHECK_HIP(hipStreamSynchronize(s));
+  if (err) {
+    SGPO_CHECK_HIP(hipMemsetAsync(a->counts + 2, 0, 4, s));
+    sgpo_set_error("acq_update: hash table full while sweeping tombstones (table %zu slots)", a->table);
+    return SGPO_ERR_WORKSPACE;
+  }
+  return SGPO_OK;
+}
+
 extern "C" int sgpo_acq_update(sgpo_acq* a, const int64_t* tokens, int N, int n_needed, int scope, int round,
                                int64_t* kept_idx, int* n_kept, int* n_admissible, void* stream) {
   SGPO_REQUIRE(a && n_kept, "acq_update: null handle or n_kept");
@@ -364,8 +429,10 @@ extern "C" int sgpo_acq_update(sgpo_acq* a, const int64_t* tokens, int N, int n_
   const bool fits = (size_t)host[0] <= room && !host[2];
   // not fitting: the same kernel with n_needed = 0 appends nothing and releases the slots this batch claimed
   hipLaunchKernelGGL(acq_commit_kernel, dim3((N + 3) / 4), dim3(256), 0, s, a->d, tokens, N, a->n_store,
-                     fits ? n_needed : 0, round, a->slot_of, a->flag, a->rank);
+                     fits ? n_needed : 0, round, a->slot_of, a->flag, a->rank, a->counts + 3);
   SGPO_CHECK_HIP(hipGetLastError());
+  int n_tomb = 0;
+  SGPO_CHECK_HIP(hipMemcpyAsync(&n_tomb, a->counts + 3, sizeof(int), hipMemcpyDeviceToHost, s));
   SGPO_CHECK_HIP(hipStreamSynchronize(s));
   if (host[2]) {
     SGPO_CHECK_HIP(hipMemsetAsync(a->counts + 2, 0, 4, s));
@@ -379,6 +446,8 @@ extern "C" int sgpo_acq_update(sgpo_acq* a, const int64_t* tokens, int N, int n_
   a->n_store += (uint32_t)host[0];
   *n_kept = host[0];
   if (n_admissible) *n_admissible = host[1];
+  // live slots never exceed half the table (sgpo_acq_create); tombstones beyond an eighth of it are swept out
+  if ((size_t)n_tomb > a->table / 8) return acq_rebuild(a, s);
   return SGPO_OK;
 }
 

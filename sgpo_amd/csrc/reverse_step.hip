@@ -124,11 +124,13 @@ __device__ __forceinline__ void reverse_step_mdlm_row(
     if (lr == lr) lr = fminf(lr, 80.0f);  // torch.clamp propagates NaN, fminf would drop it
     q = q * expf(lr);
   }
-  if (guided && nan_flag && act && q != q) *nan_flag = 1;
+  if (guided && nan_flag && act && q != q) atomicOr(nan_flag, 1);   // models/mdlm.py:410-411
   if (k == xt) q += 1.0f;
-  q = fmaxf(q, 0.f);
+  q = q < 0.f ? 0.f : q;   // torch.clamp(min=0) keeps a NaN (fmaxf would turn it into 0 and hide it from the check below)
   if (!act) q = 0.f;
   const float tot = hsum32(q);
+  // torch.multinomial refuses a row whose sum is 0, inf or NaN (cls_guidance.py:52); the kernel would draw token 0
+  if (nan_flag && k == 0 && !(tot > 0.f && tot <= 3.4028234e38f)) atomicOr(nan_flag, 2);
   const float p = q / tot;
   float den = act ? noise_denominator_w(noise_mode, noise, lidx, philox_word, true) : 1.f;
   float v = act ? p / den : -INFINITY;

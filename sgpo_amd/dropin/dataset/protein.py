@@ -79,28 +79,31 @@ class ProteinPredictorDataset(DiscreteData):
                 print(f'Only found {len(seqs)} unique samples for random initialization')
             self.update_data(seqs, n_needed=n_random_init)
 
-    # ---- host helpers of the reference, unchanged in meaning (dataset/protein.py:92-135) ----
-    def get_full_sequence(self, combo):
-        seq = list(self.full_seq_string)
-        for i, r in enumerate(self.residues):
-            seq[r] = combo[i]
+    # ---- host helpers (dataset/protein.py:92-135): same results and the same draws from numpy's global RNG ----
+    _LETTERS = np.array(list('ACDEFGHIKLMNPQRSTVWY'))
+
+    def _parent_with(self, sites, letters):
+        seq = np.array(list(self.full_seq_string))
+        seq[np.asarray(sites, dtype=np.int64)] = letters
         return ''.join(seq)
 
+    def get_full_sequence(self, combo):
+        """The parent with the letters of `combo` at the designable residues (landscape rows, protein.py:92-99)."""
+        return self._parent_with(self.residues, list(combo))
+
     def sample_random_variants(self, n_samples):
-        mutation_choices = list('ACDEFGHIKLMNPQRSTVWY')
-        variants = []
-        if self.n_max_mutations is None:
-            residues = self.residues
-        elif self.n_max_mutations > self.n_residues:
-            self.n_max_mutations = self.n_residues
+        """Random variants of the parent for `n_random_init` (protein.py:108-135).  Per variant: when n_max_mutations is
+        set, first ONE draw of that many designable residues without replacement; then one letter draw per site, in
+        site order."""
+        if self.n_max_mutations is not None:
+            self.n_max_mutations = min(self.n_max_mutations, self.n_residues)
+        out = []
         for _ in range(n_samples):
-            if self.n_max_mutations is not None:
-                residues = np.random.choice(self.residues, self.n_max_mutations, replace=False)
-            seq_list = list(self.full_seq_string)
-            for r in residues:
-                seq_list[r] = np.random.choice(mutation_choices)
-            variants.append(''.join(seq_list))
-        return variants
+            sites = self.residues if self.n_max_mutations is None else \
+                np.random.choice(self.residues, self.n_max_mutations, replace=False)
+            letters = [np.random.choice(self._LETTERS) for _ in sites]
+            out.append(self._parent_with(sites, letters))
+        return out
 
     def get_length(self):
         return self.n_residues

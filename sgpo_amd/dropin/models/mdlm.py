@@ -139,24 +139,37 @@ class MDLM(GenerativeModel):
     # ------------------------------------------------------------------ reference API
     def sample(self, num_samples):
         """MDLMDiffusion._sample with the ddpm predictor + noise removal (mdlm_diffusion.py:661-700)."""
-        eps = 1e-5
-        n = self.timestep
         x = self.get_start(num_samples)
-        timesteps = torch.linspace(1, eps, n + 1)
-        dt = (1 - eps) / n
-        for i in range(n):
-            t = timesteps[i]
-            sig_t, _ = self.model.noise(t)
-            sig_s, _ = self.model.noise(t - dt)
-            mt, ms = float(1 - torch.exp(-sig_t)), float(1 - torch.exp(-sig_s))
-            logits = self._denoise(x, sig_t)
-            x, _ = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_HARD,
-                                        noise_src=self.noise_source, noise=self._next_noise())
+        for i in range(self.timestep):
+            x = self.ddpm_step(x, i)
+        return self.noise_removal(x)
+
+    def _sample_grid(self, eps=1e-5):
+        """(timesteps, dt) of mdlm_diffusion.py:671-673: t runs from 1 down to eps in `self.timestep` updates."""
+        return torch.linspace(1, eps, self.timestep + 1), (1 - eps) / self.timestep
+
+    @torch.no_grad()
+    def ddpm_step(self, x, i, want_probs=False):
+        """Update i of the ancestral sampler, MDLMDiffusion._ddpm_update (mdlm_diffusion.py:634-658) at t = timesteps[i]
+        with the correct t - dt schedule (not defect D2's): carry-over of unmasked tokens, categorical draw elsewhere."""
+        timesteps, dt = self._sample_grid()
+        sig_t, _ = self.model.noise(timesteps[i])
+        sig_s, _ = self.model.noise(timesteps[i] - dt)
+        mt, ms = float(1 - torch.exp(-sig_t)), float(1 - torch.exp(-sig_s))
+        logits = self._denoise(x, sig_t)
+        xo, q = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_HARD, noise_src=self.noise_source,
+                                     noise=self._next_noise(), want_probs=want_probs)
+        return (xo, q) if want_probs else xo
+
+    @torch.no_grad()
+    def noise_removal(self, x, want_probs=False):
+        """The final argmax of the denoiser at t = eps (mdlm_diffusion.py:692-699)."""
+        timesteps, _ = self._sample_grid()
         sig, _ = self.model.noise(timesteps[-1])
         logits = self._denoise(x, sig)
-        x, _ = rt.reverse_step_mdlm(logits, x, 1.0, 0.0, self.model.mask_index, L.STEP_HARD,
-                                    noise_mode=L.NOISE_NONE)
-        return x
+        xo, q = rt.reverse_step_mdlm(logits, x, 1.0, 0.0, self.model.mask_index, L.STEP_HARD, noise_mode=L.NOISE_NONE,
+                                     want_probs=want_probs)
+        return (xo, q) if want_probs else xo
 
     def get_start(self, batch_size):
         return torch.full((batch_size, self.length), self.model.mask_index, dtype=torch.int64, device=self._dev)
@@ -232,9 +245,13 @@ class MDLM(GenerativeModel):
         return q_t
 
     @torch.no_grad()
-    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False):
+    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False, check=True):
         """One fused classifier-guidance step (sampling/cls_guidance.py:34-52): denoiser ->
-        jump log-ratios -> reverse-step kernel.  Returns the next tokens (and p if asked)."""
+        jump log-ratios -> reverse-step kernel.  Returns the next tokens (and p if asked).
+
+        check: raise right here, as the reference does inside get_guided_rates / torch.multinomial, if the step met
+        a NaN rate or a row it cannot sample from (one device-to-host read).  The sampling loop passes False and calls
+        `check_nan()` every few steps instead."""
         mt, ms, sig_t = self._move_chances(t)
         logits = self._denoise(x, sig_t)
         lr = slots = None
@@ -244,13 +261,19 @@ class MDLM(GenerativeModel):
                                      noise_src=self.noise_source, noise=self._next_noise(), log_ratio=lr,
                                      slot_of_pos=slots, guide_temp=guide_temp, want_probs=want_probs,
                                      nan_flag=self._nan_flag)
+        if check:
+            self.check_nan()
         return (xo, p) if want_probs else xo
 
     def check_nan(self):
-        """Mirror of `raise ValueError` at models/mdlm.py:410-411, checked once per inference."""
-        if int(self._nan_flag.item()) != 0:
+        """The reference's two failure modes of a guided step, read back from the kernel's flag: NaN rates
+        (`raise ValueError`, models/mdlm.py:410-411) and a row torch.multinomial would refuse (cls_guidance.py:52)."""
+        flag = int(self._nan_flag.item())
+        if flag:
             self._nan_flag.zero_()
-            raise ValueError("The rate matrix 'q_t' contains NaNs.")
+            if flag & 1:
+                raise ValueError("The rate matrix 'q_t' contains NaNs.")
+            raise RuntimeError('invalid multinomial distribution (sum of guided rates is 0, inf or nan)')
 
     def _nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t):
         from .nos_step import nos_denoise

@@ -10,56 +10,58 @@ from models.base import cfg_get
 
 
 class Algo(ABC):
+    N_STANDARD = 20     # the standard amino acids lead the alphabet; whatever follows is a special character
+
     def __init__(self, net, forward_op=None, data_config=None, n_max_mutations=None, device='cuda', causal_LM=False):
-        self.net = net
-        self.forward_op = forward_op
-        self.data_config = data_config
+        self.net, self.forward_op, self.data_config = net, forward_op, data_config
         self.n_max_mutations = n_max_mutations
-        dev = getattr(net, '_dev', None)
-        self.device = dev if dev is not None else device
+        self.device = getattr(net, '_dev', None) or device      # the rank's own GPU when the net is HIP-backed
 
-        alphabet = cfg_get(data_config, 'alphabet')
-        self.alphabet = list(alphabet[:20])  # only the 20 standard amino acids
-        self.special_tokens = list(alphabet[20:])
-
+        letters = cfg_get(data_config, 'alphabet')
+        self.alphabet, self.special_tokens = list(letters[:self.N_STANDARD]), list(letters[self.N_STANDARD:])
         self.seq_len = cfg_get(data_config, 'seq_len')
-        full_seq = cfg_get(data_config, 'full_seq')
-        self.full_seq = [self.net.tokenizer.tokenize(s) for s in full_seq] if not causal_LM else full_seq
-        self.full_seq_string = full_seq
-
-        residues = cfg_get(data_config, 'residues')
-        if residues is None:
-            self.residues = list(range(self.seq_len))
-        else:
-            self.residues = [i - 1 for i in residues]  # convert to 0-indexing
+        self.full_seq_string = cfg_get(data_config, 'full_seq')
         self.all_residues = list(range(self.seq_len))
-
+        listed = cfg_get(data_config, 'residues')               # 1-indexed in the yaml (configs/data/TrpB.yaml:6)
+        self.residues = self.all_residues[:] if listed is None else [int(r) - 1 for r in listed]
         self.n_residues = len(self.residues)
-        self.mask = torch.zeros(self.seq_len)
-        self.mask[self.residues] = 1
-        self.mask = self.mask.to(self.device).int()
-        if not causal_LM:
-            self.full_seq = torch.from_numpy(np.array(self.full_seq)).to(self.device).int().squeeze(-1)
+
+        designable = torch.zeros(self.seq_len, dtype=torch.int32)
+        designable[self.residues] = 1
+        self.mask = designable.to(self.device)
+        if causal_LM:
+            self.full_seq = self.full_seq_string
+        else:
+            ids = np.concatenate([np.atleast_1d(net.tokenizer.tokenize(ch)) for ch in self.full_seq_string])
+            self.full_seq = torch.from_numpy(ids).to(self.device).int()
+
+    # ---- string repair of the generations (sampling/base.py:40-63), numpy's global RNG as there -------------------
+    def _replace_specials(self, seq):
+        """One np.random.choice per non-standard character met while walking the ORIGINAL string (a repeated character
+        draws again, although the first draw already replaced every occurrence: defect D4's accounting, kept because
+        the draws shift everything after them in numpy's stream)."""
+        chosen = {}
+        for ch in seq:
+            if ch not in self.alphabet:
+                draw = np.random.choice(self.alphabet)
+                chosen.setdefault(ch, draw)
+        return seq.translate(str.maketrans(chosen)) if chosen else seq
+
+    def _limit_mutations(self, seq):
+        """Keep a random subset of at most n_max_mutations of the positions that differ from the parent."""
+        child = np.frombuffer(seq.encode('ascii'), dtype=np.uint8)
+        parent = np.frombuffer(self.full_seq_string.encode('ascii'), dtype=np.uint8)
+        differs = np.flatnonzero(child != parent)
+        keep = np.random.choice(differs, min(self.n_max_mutations, differs.size), replace=False)
+        out = parent.copy()
+        out[keep] = child[keep]
+        return out.tobytes().decode('ascii')
 
     def project_sequences(self, sequences):
-        new_sequences = []
-        for seq in sequences:
-            for s in seq:
-                if s not in self.alphabet:
-                    seq = seq.replace(s, np.random.choice(self.alphabet))
-            new_sequences.append(seq)
-
+        repaired = [self._replace_specials(s) for s in sequences]          # all step-1 draws come first
         if self.n_residues > 4 and self.n_max_mutations is not None:
-            for i, seq in enumerate(new_sequences):
-                mutated = [j for j, (r1, r2) in enumerate(zip(seq, self.full_seq_string)) if r1 != r2]
-                max_mutations = min(self.n_max_mutations, len(mutated))
-                mutated = np.random.choice(mutated, max_mutations, replace=False)
-                seq = list(seq)
-                for j, r in enumerate(seq):
-                    if j not in mutated:
-                        seq[j] = self.full_seq_string[j]
-                new_sequences[i] = ''.join(seq)
-        return new_sequences
+            repaired = [self._limit_mutations(s) for s in repaired]
+        return repaired
 
     def project_tokens(self, x, generator=None):
         """`project_sequences` on the token tensor (N, L) itself (HIP kernel):

@@ -14,6 +14,8 @@ from .base import Algo
 
 
 class Classifier_Guidance_Inpaint(Algo):
+    NAN_CHECK_EVERY = 16
+
     def __init__(self, net, data_config, forward_op=None, temperature=1, n_max_mutations=None, device='cuda'):
         super().__init__(net=net, forward_op=forward_op, data_config=data_config, n_max_mutations=n_max_mutations,
                          device=device)
@@ -31,15 +33,20 @@ class Classifier_Guidance_Inpaint(Algo):
         timesteps = tqdm.tqdm(timesteps) if verbose else timesteps
         x = self.net.get_start(num_samples)
         fused = hasattr(self.net, 'guided_step')
-        for t in timesteps:
+        check = getattr(self.net, 'check_nan', None) if fused else None
+        for i, t in enumerate(timesteps):
             if fused:
-                x = self.net.guided_step(x, t, self.forward_op, self.temperature)
+                x = self.net.guided_step(x, t, self.forward_op, self.temperature, check=False)
+                # the reference raises at the offending step (models/mdlm.py:410-411); reading the kernel's flag costs a
+                # device sync, so it is read every NAN_CHECK_EVERY steps and after the last one
+                if check is not None and (i + 1) % self.NAN_CHECK_EVERY == 0:
+                    check()
             else:
                 x = self._generic_step(x, t)
             if inpaint:
                 x = self.project(x)
-        if fused and hasattr(self.net, 'check_nan'):
-            self.net.check_nan()
+        if check is not None:
+            check()
         x = self.project(x)
         if detokenize:
             detokenized = self.project_sequences(self._untokenize_batch(x))

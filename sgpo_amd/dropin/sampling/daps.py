@@ -65,30 +65,36 @@ class DAPS(Algo):
                           noise_src=getattr(self.net, 'noise_source', None), r_idx=inj[0], r_val=inj[1], r_u=inj[2])
 
     def _metropolis_hasting_generic(self, x0hat, op, y, sigma, steps, alpha):
-        """sampling/daps.py:75-114 verbatim in structure, for arbitrary `op.log_likelihood`."""
-        residues = torch.tensor(self.residues, device=x0hat.device)
-        n_res = residues.shape[0]
-        x = x0hat.clone()
-        dim = self.net.S
-        N = x0hat.shape[0]
-        sigma = torch.as_tensor(sigma, device=x0hat.device)
-        cur_ll = op.log_likelihood(x, y) * alpha
-        cur_hm = (x != x0hat).sum(dim=-1)
+        """The chain of sampling/daps.py:75-114 for a predictor without a fused kernel (any `op.log_likelihood`, e.g. a
+        GP draw), in torch on whatever device x0hat lives on.  Per step the torch global generator is asked, in this
+        order, for the proposal sites (randint over the designable residues), the proposal letters (randint over the
+        S states) and the acceptance uniforms -- the order the reference draws them in."""
+        dev = x0hat.device
+        sites = torch.as_tensor(self.residues, device=dev)
+        n_chains, n_states = x0hat.shape[0], self.net.S
+        noise_level = torch.as_tensor(sigma, device=dev) / self.beta
+
+        def prior_term(distance):                         # log N(x0hat -> x) of daps.py:68-73 at this noise level
+            return self.log_ratio(noise_level, distance)
+
+        state = x0hat.clone()
+        score = op.log_likelihood(state, y) * alpha
+        dist = torch.zeros(n_chains, dtype=torch.int64, device=dev)
         for _ in range(steps):
-            proposal = x.clone()
-            idx = residues[torch.randint(n_res, (N,), device=x.device)]
-            v = torch.randint(dim, (N,), device=x.device)
-            proposal.scatter_(1, idx[:, None], v.unsqueeze(1))
-            ll = op.log_likelihood(proposal, y) * alpha
-            hm = (proposal != x0hat).sum(dim=-1)
-            lr = ll - cur_ll
-            lr += self.log_ratio(sigma / self.beta, hm) - self.log_ratio(sigma / self.beta, cur_hm)
-            rho = torch.clip(torch.exp(lr), max=1.0)
-            seed = torch.rand_like(rho)
-            x = x * (seed > rho).unsqueeze(-1) + proposal * (seed < rho).unsqueeze(-1)
-            cur_ll = ll * (seed < rho) + cur_ll * (seed > rho)
-            cur_hm = hm * (seed < rho) + cur_hm * (seed > rho)
-        return x
+            where = sites[torch.randint(sites.numel(), (n_chains,), device=dev)]
+            letter = torch.randint(n_states, (n_chains,), device=dev)
+            cand = state.scatter(1, where[:, None], letter[:, None])
+            cand_score = op.log_likelihood(cand, y) * alpha
+            cand_dist = (cand != x0hat).sum(dim=-1)
+            log_accept = cand_score - score
+            log_accept = log_accept + (prior_term(cand_dist) - prior_term(dist))
+            accept_p = torch.exp(log_accept).clamp(max=1.0)
+            u = torch.rand_like(accept_p)
+            take, stay = u < accept_p, u > accept_p       # u == accept_p selects neither (daps.py:110-112): kept
+            state = state * stay[:, None] + cand * take[:, None]
+            score = cand_score * take + score * stay
+            dist = cand_dist * take + dist * stay
+        return state
 
     def uncond_sample(self, net, xt, t_start, inpaint=False):
         timesteps = torch.linspace(int(t_start), 0, self.ode_steps, dtype=int)
@@ -98,26 +104,26 @@ class DAPS(Algo):
                 xt = self.project(xt)
         return xt
 
+    def _sigma_at(self, t):
+        """Noise level of annealing time t: a table for D3PM (models/d3pm.py:29), a function for MDLM (daps.py:139-142)."""
+        if self.type == 'D3PM':
+            table = getattr(self.net, '_sigma_cpu', None)
+            return (table if table is not None else self.net.sigma)[t]
+        return self.net.sigma(t)
+
     @torch.no_grad()
     def inference(self, observation=None, num_samples=1, verbose=True, detokenize=False, inpaint=False):
-        pbar = tqdm.trange(self.num_steps) if verbose else range(self.num_steps)
+        """sampling/daps.py:127-164: per annealing time a few-step reverse "ODE" to x0hat, Metropolis-Hastings around it
+        under the value function, then re-noising to the next annealing time (not after the last one)."""
+        last = self.num_steps - 1
         xt = self.net.get_start(num_samples)
-        for i in pbar:
-            x0hat = self.uncond_sample(self.net, xt, self.time_steps[i], inpaint)
-            if self.type == 'D3PM':
-                sigma = self.net._sigma_cpu[self.time_steps[i]] if hasattr(self.net, '_sigma_cpu') \
-                    else self.net.sigma[self.time_steps[i]]
-            else:
-                sigma = self.net.sigma(self.time_steps[i])
-            if self.alpha == 0:
-                x0y = x0hat
-            else:
-                x0y = self.metropolis_hasting(x0hat, self.forward_op, observation, sigma, steps=self.mh_steps,
-                                              alpha=self.alpha, inpaint=inpaint)
-            if i == self.num_steps - 1:
-                xt = x0y
-                break
-            xt = self.net.q_sample(x0y, self.time_steps[i + 1].repeat(num_samples))
+        for i in (tqdm.trange(self.num_steps) if verbose else range(self.num_steps)):
+            t_now = self.time_steps[i]
+            x0 = self.uncond_sample(self.net, xt, t_now, inpaint)
+            if self.alpha != 0:
+                x0 = self.metropolis_hasting(x0, self.forward_op, observation, self._sigma_at(t_now), steps=self.mh_steps,
+                                             alpha=self.alpha, inpaint=inpaint)
+            xt = x0 if i == last else self.net.q_sample(x0, self.time_steps[i + 1].repeat(num_samples))
         xt = self.project(xt)
         if detokenize:
             return xt, self.project_sequences(self._untokenize_batch(xt))

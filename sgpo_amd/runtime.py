@@ -625,9 +625,6 @@ def q_sample_d3pm(x, t, q_bar_all, S, noise_src=None, noise=None):
     return out
 
 
-_mh_ws = {}
-
-
 def daps_mh(vf, x0hat, residues, S, log_alpha, log_1alpha, alpha, steps, noise_src=None, r_idx=None, r_val=None,
             r_u=None):
     """DAPS.metropolis_hasting on the GPU.  vf: MlpValueFunction; residues: 0-indexed mutable positions."""
@@ -635,13 +632,20 @@ def daps_mh(vf, x0hat, residues, S, log_alpha, log_1alpha, alpha, steps, noise_s
     N, Lq = x0hat.shape
     x0hat = x0hat.contiguous()
     dev = x0hat.device
-    key = (id(vf), tuple(residues), str(dev))
-    if key not in _mh_ws:
+    residues = [int(r) for r in residues]
+    # the kernel indexes x0hat / x_out rows with these positions: refuse anything outside the row here
+    if not residues or min(residues) < 0 or max(residues) >= Lq:
+        raise L.SgpoError(f'daps_mh: mutable positions {residues} outside a length-{Lq} row')
+    # device copies of the position list, its read-slot map and the kernel workspace live ON the value function they
+    # were built for (it is rebuilt after every retraining), so nothing outlives it and no other model can pick them up
+    cache = vf.__dict__.setdefault('_mh_cache', {})
+    key = (tuple(residues), str(dev))
+    if key not in cache:
         slot = [vf.read_pos.index(r) if r in vf.read_pos else -1 for r in residues]
-        _mh_ws[key] = (torch.tensor(list(residues), dtype=torch.int32, device=dev),
-                       torch.tensor(slot, dtype=torch.int32, device=dev),
-                       torch.empty(512, dtype=torch.uint8, device=dev))
-    d_res, d_slot, ws = _mh_ws[key]
+        cache[key] = (torch.tensor(residues, dtype=torch.int32, device=dev),
+                      torch.tensor(slot, dtype=torch.int32, device=dev),
+                      torch.empty(512, dtype=torch.uint8, device=dev))
+    d_res, d_slot, ws = cache[key]
     base = (ws.data_ptr() + 255) & ~255
     if r_idx is not None:
         noise_mode = L.NOISE_UNIFORM

@@ -72,8 +72,8 @@ def test_project_tokens_rejects_bad_input(rt):
     assert int(y[2, 3]) == 19
 
 
-def _run_script(rt, calls, L):
-    dev_set = rt.AcquisitionSet(L, capacity=4096, max_batch=256)
+def _run_script(rt, calls, L, capacity=4096, max_batch=256):
+    dev_set = rt.AcquisitionSet(L, capacity=capacity, max_batch=max_batch)
     store = acq.SequenceStore()
     has_seqs, round_start, cur_round = False, None, 0
     for c in calls:
@@ -101,6 +101,7 @@ def _run_script(rt, calls, L):
     tokens, rounds = dev_set.read()
     got = [''.join(ALPHABET[t] for t in row) for row in tokens.cpu().tolist()]
     assert got == store.seqs and rounds.cpu().tolist() == store.rounds
+    return len(got)
 
 
 def test_acquisition_set_follows_update_data_scripts(rt):
@@ -139,6 +140,26 @@ def test_acquisition_set_large_random_against_restatement(rt):
     # properties: under BO nothing is admitted twice; a replayed batch adds nothing
     kept, adm = dev_set.update(torch.from_numpy(x).cuda(), 10 ** 6, 1, 9)
     assert kept.numel() == 0 and adm == 0
+
+
+def test_acquisition_set_survives_many_truncated_rounds(rt):
+    """Rows cut off by n_needed give their slot up as a tombstone; tombstones are swept (the table is refilled from the
+    store) before they can fill it.  60 updates of up to 64 rows with n_needed = 3 make about 3000 tombstones in a
+    1024-slot table; every update must still agree with the restatement, including rows that come back later and
+    the round-scoped filter (scope 2) after a sweep."""
+    L = 20
+    rng = np.random.default_rng(3)
+    pool = [''.join(ALPHABET[t] for t in rng.integers(0, 20, L)) for _ in range(6000)]
+    calls, seen = [], 0
+    for it in range(60):
+        fresh = pool[seen:seen + 56]
+        seen += 56
+        batch = fresh + [pool[i] for i in rng.integers(0, seen, 8)]     # some rows met before
+        rng.shuffle(batch)
+        calls.append(dict(batch=batch, n_needed=3, BO=(it % 5 != 4), round=it // 10, unique_only=True, truncated=True,
+                          diverged=True))
+    n = _run_script(rt, calls, L, capacity=400, max_batch=64)
+    assert n == 180
 
 
 def test_acquisition_set_hash_collisions_are_resolved_by_token_compare(rt):

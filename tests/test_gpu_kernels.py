@@ -364,6 +364,51 @@ def test_cg_step_against_golden(rt):
     assert torch.equal(xo.cpu()[ok], x_ref[ok])
 
 
+def test_guided_step_flags_nan_rates_and_rows_it_cannot_sample(rt):
+    """models/mdlm.py:410-411 raises on NaN guided rates and torch.multinomial (cls_guidance.py:52) on a row whose sum is
+    0, inf or NaN: the kernel reports both through nan_flag (bits 0 and 1) and the drop-in raises at the step."""
+    from sgpo_amd import _lib as L
+    MASK, K, B, Lq = 28, 31, 3, 10
+    g = torch.Generator().manual_seed(2)
+    logits = torch.randn(B, Lq, K, generator=g).cuda()
+    x = torch.randint(0, 26, (B, Lq), generator=g)
+    x[:, ::2] = MASK
+    x = x.cuda()
+    e = torch.empty(B, Lq, K).exponential_(1, generator=g)
+    flag = torch.zeros(1, dtype=torch.int32, device='cuda')
+    lr = torch.zeros(B, Lq, K, device='cuda')
+    rt.reverse_step_mdlm(logits, x, 0.6, 0.3, MASK, L.STEP_SOFT_CG, noise=e, log_ratio=lr, guide_temp=0.5, nan_flag=flag)
+    assert int(flag.item()) == 0
+    lr[1, 4, 7] = float('nan')                                    # a NaN log-ratio at a masked position
+    rt.reverse_step_mdlm(logits, x, 0.6, 0.3, MASK, L.STEP_SOFT_CG, noise=e, log_ratio=lr, guide_temp=0.5, nan_flag=flag)
+    assert int(flag.item()) & 1
+    flag.zero_()
+    bad = logits.clone()
+    bad[2, 6] = float('inf')                                      # unguided: the row's probabilities are NaN
+    rt.reverse_step_mdlm(bad, x, 0.6, 0.3, MASK, L.STEP_SOFT_CG, noise=e, nan_flag=flag)
+    assert int(flag.item()) == 2
+    # through the drop-in: raised at the step, and the flag is cleared for the next call
+    import sgpo_amd
+    sgpo_amd.install_dropin()
+    from models.mdlm import MDLM
+    from problem.protein import ProteinPredictor
+    from sgpo_amd import weights as W
+    dims = dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2)
+    net = MDLM('synthetic', dict(model=dict(hidden_size=128, cond_dim=32, n_blocks=1, n_heads=2)), None, num_steps=16,
+               seq_len=Lq, device='cuda:0', state_dict=W.dit_synthetic_state(seed=1, vocab=31, **dims))
+    dc = dict(alphabet='ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!', alphabet_size=31, seq_len=Lq, full_seq='M' * Lq, residues=None)
+    pred = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+    msd = W.mlp_synthetic_state(seed=4, n_residues=Lq)
+    msd['cls_head.2.weight'] = torch.full((1, 64), float('nan'))  # f = NaN for every jump -> every evaluated ratio NaN
+    pred.model.load_state_dict(msd)
+    pred.eval()
+    with pytest.raises(ValueError, match='NaNs'):
+        net.guided_step(x, torch.tensor(9), pred, 0.5)
+    pred.model.load_state_dict(W.mlp_synthetic_state(seed=4, n_residues=Lq))
+    pred.eval()
+    net.guided_step(x, torch.tensor(9), pred, 0.5)                 # healthy again
+
+
 def test_philox_sampler_statistics_and_shard_invariance(rt):
     from sgpo_amd.runtime import NoiseSource, categorical_sample
     K = 31

@@ -170,21 +170,64 @@ def test_get_guided_rates_signature(env):
     assert net.get_guided_rates(pred, xs, 9, q, guide_temp=0) is q
 
 
-def test_mdlm_sample_uncond(env):
+@pytest.mark.parametrize('name', ['mdlm_sample_small', 'mdlm_sample_real'])
+def test_mdlm_sample_uncond_teacher_forced(env, name):
+    """Row a-15, `MDLM.sample` (Uncond path; mdlm_diffusion.py:634-700), walked along the REFERENCE's own states (golden
+    `states`: what the reference handed to its denoiser before every update and before the final argmax):
+    per update the device's reverse probabilities within the logit tolerance and its tokens equal to the reference's next
+    state wherever the race cannot flip inside it; carry-over exact; the noise-removal argmax equal wherever the top
+    two log-probabilities are further apart than the tolerance.  `mdlm_sample_real`: real DiT dims, CreiLOV length."""
     from models.mdlm import MDLM
+    from oracle import dit as odit
+    from oracle import mdlm as omdlm
     from sgpo_amd import weights as W
-    g = load_golden('mdlm_sample_small')
+    from tf_common import LOGIT_RTOL
+    g = load_golden(name)
     dims = dict(zip(DIM_KEYS, [int(v) for v in g['dims']]))
     sd = W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
     cfg = dict(model=dict(hidden_size=dims['hidden'], cond_dim=dims['cond_dim'], n_blocks=dims['n_blocks'],
                           n_heads=dims['n_heads']))
     B, Lq = g['x'].shape
-    net = MDLM('synthetic', cfg, None, num_steps=int(g['T']), seq_len=Lq, device='cuda:0', state_dict=sd)
+    T = int(g['T'])
+    states = g['states'].long()
+    assert states.shape[0] == T + 1 and torch.equal(states[0], torch.full((B, Lq), 28))
+    net = MDLM('synthetic', cfg, None, num_steps=T, seq_len=Lq, device='cuda:0', state_dict=sd)
+    timesteps = torch.linspace(1, 1e-5, T + 1)
+    dt = (1 - 1e-5) / T
+    tf = TeacherForced()
+    for i in range(T):
+        xs, u = states[i], g['us'][i]
+        z = odit.dit_forward(sd, xs, torch.zeros(B))
+        logp = omdlm.subs_parameterization(z, xs, 28)
+        mt = 1 - torch.exp(-omdlm.total_noise(timesteps[i]))
+        ms = 1 - torch.exp(-omdlm.total_noise(timesteps[i] - dt))
+        q_ref = logp.exp() * (mt - ms)
+        q_ref[:, :, 28] = ms
+        x_ref = omdlm.ddpm_update(sd, xs, timesteps[i] * torch.ones(B, 1), dt, 28, u)
+        assert torch.equal(x_ref, states[i + 1])                  # the oracle walks the reference's trajectory
+        net.injected_noise.append(u)
+        xo, q = net.ddpm_step(xs.cuda(), i, want_probs=True)
+        masked = xs == 28
+        # the race of _sample_categorical is q / (1e-10 - log(u + 1e-10)): hand the helper that denominator
+        ok = tf.step(i, q.cpu()[masked], q_ref[masked], xo.cpu()[masked], x_ref[masked], (1e-10 - (u + 1e-10).log())[masked],
+                     float(z.abs().max()))
+        assert torch.equal(xo.cpu()[~masked], xs[~masked])        # carry-over
+    tf.finish(name)
+    # noise removal: plain argmax of the subs-parameterised log-probabilities at the last state
+    xs = states[T]
+    z = odit.dit_forward(sd, xs, torch.zeros(B))
+    logp = omdlm.subs_parameterization(z, xs, 28)
+    assert torch.equal(logp.argmax(-1), g['x'])
+    xo = net.noise_removal(xs.cuda()).cpu()
+    top2 = logp.topk(2, dim=-1).values
+    sure = (top2[..., 0] - top2[..., 1]) > 2 * LOGIT_RTOL * float(z.abs().max())
+    assert torch.equal(xo[sure], g['x'][sure]) and float(sure.float().mean()) > 0.9
+    # and the free run on the same uniforms stays close to the reference's result
     for u in g['us']:
         net.injected_noise.append(u)
     x = net.sample(B).cpu()
-    # free-running with bf16 logits: agreement with the reference trajectory is high but not exact
     agree = (x == g['x']).float().mean().item()
+    print(f'{name}: free run agrees with the reference on {agree:.4f} of the positions')
     assert agree > 0.9, agree
     assert int((x == 28).sum()) == 0
 

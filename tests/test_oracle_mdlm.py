@@ -63,11 +63,19 @@ def test_udlm_p_sample():
         assert torch.equal(xh, g[f'hard_t{t}'])
 
 
-def test_mdlm_sample():
-    g = load_golden('mdlm_sample_small')
+@pytest.mark.parametrize('name', ['mdlm_sample_small', 'mdlm_sample_real'])
+def test_mdlm_sample(name):
+    g = load_golden(name)
     sd = _sd(g)
-    x = omdlm.sample(sd, g['x'].shape[0], g['x'].shape[1], int(g['T']), 28, g['us'])
+    B, L = g['x'].shape
+    T = int(g['T'])
+    x = omdlm.sample(sd, B, L, T, 28, g['us'])
     assert torch.equal(x, g['x'])
+    # update by update along the reference's own states (what it handed to its denoiser)
+    states = g['states'].long()
+    ts, dt = torch.linspace(1, 1e-5, T + 1), (1 - 1e-5) / T
+    for i in range(T):
+        assert torch.equal(omdlm.ddpm_update(sd, states[i], ts[i] * torch.ones(B, 1), dt, 28, g['us'][i]), states[i + 1]), i
 
 
 def test_mlp():

@@ -144,16 +144,32 @@ def gen_mdlm():
             out[f'u_t{t}'] = u
     save('udlm_small', **out)
 
-    # MDLM.sample (Uncond path): _sample with ddpm predictor, 6 steps
-    net, core, sd = build_ref_mdlm(SMALL, seed=14, L=L, T=6)
-    core.length = L
-    core.config.eval_batch_size = B
-    torch.manual_seed(9)
-    us = [torch.rand(B, L, 31) for _ in range(6)]
-    torch.manual_seed(9)
-    with torch.no_grad():
-        xs = net.sample(B)
-    save('mdlm_sample_small', seed=14, dims=np.array(list(SMALL.values())), us=torch.stack(us), x=xs, T=6)
+    gen_mdlm_sample()
+
+
+def gen_mdlm_sample():
+    """MDLM.sample (the Uncond path, sampling/uncond.py:63-64): MDLMDiffusion._sample with the ddpm predictor and noise
+    removal (mdlm_diffusion.py:661-700).  Stores the uniforms, the result and the state handed to the denoiser before
+    every update and before the final argmax (spy on core.forward)."""
+    for name, dims, seed, B, L, T in (('mdlm_sample_small', SMALL, 14, 3, 37, 6), ('mdlm_sample_real', REAL, 21, 2, 119, 8)):
+        net, core, sd = build_ref_mdlm(dims, seed=seed, L=L, T=T)
+        core.length = L
+        core.config.eval_batch_size = B
+        states = []
+        fwd = core.forward
+
+        def spy(x, sigma, _fwd=fwd, _states=states):
+            _states.append(x.clone())
+            return _fwd(x, sigma)
+        core.forward = spy
+        torch.manual_seed(9)
+        us = [torch.rand(B, L, 31) for _ in range(T)]
+        torch.manual_seed(9)
+        with torch.no_grad():
+            xs = net.sample(B)
+        assert len(states) == T + 1
+        save(name, seed=seed, dims=np.array(list(dims.values())), us=torch.stack(us), x=xs, T=T,
+             states=torch.stack(states).to(torch.int8))
 
 
 def data_cfg(name):
@@ -880,7 +896,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
