@@ -178,6 +178,15 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     n_my = tot > t_first ? (tot - t_first + t_stride - 1) / t_stride : 0;
   }
   if (n_my == 0) return;
+#ifdef SGPO_GEMM_ABLATE
+  // Diagnostic build only: half of the workgroups of every XCD start `dbg >> 8` microseconds late, so that their
+  // HBM-bound epilogues would fall into the other half's MFMA-bound K loops instead of all at once.  Measured (round
+  // 2): no gain at 15 / 30 / 45 us on any of the three GEMMs -- the start offset does not survive.
+  if ((dbg >> 8) && (blockIdx.x & 8)) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), ticks = (unsigned long long)(dbg >> 8) * 100ull;
+    while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(64);
+  }
+#endif
   auto tile_origin = [&](int i, int& m0, int& n0) {
     const int j = t_first + i * t_stride;
     if (grouped) { m0 = ((j / ntn) * 8 + xcd) * BM; n0 = (j % ntn) * BN; }
@@ -753,6 +762,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   }
 #ifdef SGPO_GEMM_ABLATE
   { const char* e = getenv("SGPO_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
+  { const char* e = getenv("SGPO_GEMM_STAGGER_US"); dbg = (dbg & 255) | ((e ? atoi(e) : 0) << 8); }
 #endif
 #ifdef SGPO_GEMM_STAMP
   { const char* e = getenv("SGPO_GEMM_STAMP_EPI"); dbg = (e && atoi(e) == epi) ? 8 : 0; }

@@ -5,6 +5,15 @@ data-path collective: rank r samples rows [lo, hi) with Philox counters offset b
 (shard-invariant noise).  The only exchange is one all-gather per batch of the generated tokens
 (uint8) and their scores (fp32) -- RCCL over xGMI on GPUs (`backend='nccl'`), gloo on CPU for tests.
 One process per GPU; launch with torch.distributed.run.
+
+Three ways to cut the work, all ending in that one all-gather:
+  * `sharded_inference`  -- rows of ONE batch over the ranks (BASELINE config 3: 16384 = 8 x 2048);
+  * `run_cells`          -- independent sampler calls, one (guidance strength, repeat) cell each, dealt to the
+                            ranks (config 4: pareto.py:131-164 loops over them one after the other);
+  * `thompson_round`     -- Thompson draws of an ensemble (config 5: iterativeBO.py:204-237), a wave of
+                            `world` draws at a time, consumed in draw order so the result equals the
+                            one-rank loop; `share_members` hands every rank the weights of the members
+                            that were trained elsewhere.
 """
 import os
 
@@ -87,3 +96,126 @@ def sharded_inference(algo, num_samples, seed, rank=None, world=None, score_fn=N
     if score_fn is not None:
         s = score_fn(x) if hi > lo else torch.empty(0, dtype=torch.float32, device=x.device)
     return gather_samples(x, s)
+
+
+# ---------------------------------------------------------------------------------------------------------
+# Work that is cut by CALL instead of by row (configs 4 and 5)
+
+def _world(rank, world, group=None):
+    if world is None:
+        on = dist.is_available() and dist.is_initialized()
+        return (dist.get_rank(group) if on else 0), (dist.get_world_size(group) if on else 1)
+    return rank, world
+
+
+def deal(n_items, rank, world):
+    """Items [0, n_items) dealt round-robin: rank r takes r, r + world, ...  (cells / draws cost the same, so the
+    deal is balanced to within one item)."""
+    return list(range(rank, n_items, world))
+
+
+def item_seed(seed, index):
+    """Philox key of item `index` of a job keyed by `seed`: the same on whichever rank runs the item, different
+    for every item (splitmix64 of the pair)."""
+    z = (int(seed) * 0x9E3779B97F4A7C15 + int(index) + 1) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return z ^ (z >> 31)
+
+
+def gather_tagged(tokens, scores, tags, group=None):
+    """One ragged all-gather of rows that carry an item tag: tokens (n, L), scores (n,) fp32 or None, tags (n,)
+    int64.  Returns the rows of all ranks sorted by (tag, original order): {tag: (tokens uint8, scores)}."""
+    t, s = gather_samples(tokens, scores, group=group)
+    # the tags ride along as a second byte matrix (8 bytes per row) in the same padded layout
+    tag_bytes = tags.to(torch.int64).contiguous().view(torch.uint8).reshape(-1, 8)
+    g, _ = gather_samples(tag_bytes, None, group=group)
+    all_tags = g.contiguous().view(torch.int64).reshape(-1)
+    out = {}
+    for tag in sorted(set(all_tags.tolist())):
+        rows = torch.nonzero(all_tags == tag).squeeze(-1)
+        out[int(tag)] = (t[rows], None if s is None else s[rows])
+    return out
+
+
+def run_cells(cells, run_cell, seed, rank=None, world=None, group=None):
+    """Independent sampler calls dealt over the ranks (config 4: the (guidance strength, repeat) grid of pareto.py:131-164).
+
+    cells: list of picklable descriptions, the same list on every rank.  run_cell(cell, key) -> (tokens (b, L) int,
+    scores (b,) or None) runs ONE cell whole on the calling rank with `key = item_seed(seed, index)` as its Philox key
+    (so a cell's samples do not depend on which rank, or how many ranks, ran the job).  Returns, on every rank, the
+    list of (tokens uint8, scores) in cell order after ONE all-gather of everything this rank produced."""
+    rank, world = _world(rank, world, group)
+    mine = deal(len(cells), rank, world)
+    toks, scs, tags = [], [], []
+    have_scores = None
+    for i in mine:
+        x, sc = run_cell(cells[i], item_seed(seed, i))
+        toks.append(x)
+        tags.append(torch.full((x.shape[0],), i, dtype=torch.int64, device=x.device))
+        have_scores = sc is not None if have_scores is None else have_scores
+        if sc is not None:
+            scs.append(sc.to(torch.float32))
+    if world == 1:
+        return [(toks[k].to(torch.uint8), scs[k] if have_scores else None) for k in range(len(cells))]
+    if not toks:        # more ranks than cells: an empty contribution (the collective still needs every rank)
+        raise ValueError('run_cells: every rank needs at least one cell (len(cells) >= world); run fewer ranks')
+    merged = gather_tagged(torch.cat(toks), torch.cat(scs) if have_scores else None, torch.cat(tags), group=group)
+    return [merged[i] for i in range(len(cells))]
+
+
+def share_members(local, n_members, rank=None, world=None, group=None):
+    """Ensemble weights after sharded training (config 5): member m was trained on rank m % world and `local[m]` holds
+    its flat fp32 blob there.  Returns the list of all n_members blobs on every rank (one broadcast per member from
+    its owner: 2 MB each for the CreiLOV value function)."""
+    rank, world = _world(rank, world, group)
+    if world == 1:
+        return [local[m] for m in range(n_members)]
+    ref = next(iter(local.values()))
+    out = []
+    for m in range(n_members):
+        owner = m % world
+        buf = local[m].contiguous() if owner == rank else torch.empty_like(ref)
+        dist.broadcast(buf, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
+        out.append(buf)
+    return out
+
+
+def thompson_round(draw, consume, n_needed, max_draws, pick_member, seed, rank=None, world=None, group=None):
+    """One acquisition round of Thompson sampling over an ensemble (iterativeBO.py:204-237) on `world` ranks.
+
+    The reference loops: pick a member (numpy RNG), sample a small batch guided by it, hand the batch to update_data,
+    stop when the round has its new sequences or after max_iterations draws.  Draws are independent given
+    (member, key), so they are computed a wave of `world` at a time -- rank r computes draw wave * world + r -- and
+    all-gathered once per wave; every rank then CONSUMES the wave in draw order and stops at the same draw the
+    one-rank loop would have stopped at (draws of the wave beyond that point are dropped unseen).
+      pick_member() -> member index; called once per draw, in draw order, on EVERY rank (same numpy seed on all
+                       ranks, as util/seed.py sets it, keeps the streams in step);
+      draw(member, key) -> (tokens (b, L), scores (b,) or None), this rank's sampler call;
+      consume(tokens uint8, scores) -> number of new sequences accepted (update_data on every rank, or on rank 0
+                       with the count broadcast by the caller).
+    Returns (n_new, n_draws_consumed)."""
+    rank, world = _world(rank, world, group)
+    n_new = k = 0
+    while n_new < n_needed and k < max_draws:
+        # a full wave is always computed, also when fewer than `world` draws remain before max_draws: the surplus is
+        # dropped below (pick_member is thereby called up to world - 1 times more than in the one-rank loop; the
+        # reference reseeds numpy at the start of every round, iterativeBO.py:202, so rounds stay reproducible)
+        wave = list(range(k, k + world))
+        members = [pick_member() for _ in wave]
+        d, m = wave[rank], members[rank]
+        x, sc = draw(m, item_seed(seed, d))
+        if world == 1:
+            got = {d: (x.to(torch.uint8), sc)}
+        else:
+            tag = torch.full((x.shape[0],), d, dtype=torch.int64, device=x.device)
+            got = gather_tagged(x, sc, tag, group=group)
+        for d in wave:
+            if n_new >= n_needed or d >= max_draws:
+                break
+            t, sc = got[d]
+            n_new += int(consume(t, sc))
+            k = d + 1
+        else:
+            k = wave[-1] + 1
+    return n_new, k

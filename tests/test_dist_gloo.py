@@ -88,3 +88,87 @@ def test_gather_samples_single_process():
     x = torch.randint(0, 31, (5, 9))
     t, s = gather_samples(x, None)
     assert t.dtype == torch.uint8 and torch.equal(t.long(), x) and s is None
+
+
+# ---- work cut by call: the (strength, repeat) grid of config 4 and the Thompson draws of config 5 ----------------
+def _stub_cell(cell, key):
+    """A 'sampler call' whose rows depend only on (cell, key): what a seeded inference() of that cell returns."""
+    coef, rep, b = cell
+    g = torch.Generator().manual_seed(key & 0x7FFFFFFFFFFFFFFF)
+    x = torch.randint(0, 31, (b, 13), generator=g)
+    return x, x.float().sum(1) * coef + rep
+
+
+def _stub_draw(member, key):
+    g = torch.Generator().manual_seed((key ^ (member * 7919)) & 0x7FFFFFFFFFFFFFFF)
+    x = torch.randint(0, 4, (6, 5), generator=g)        # few distinct rows: duplicates between draws are common
+    return x, x.float().sum(1) + member
+
+
+class _Store:
+    """update_data with BO=True in miniature: unique rows not seen before, truncated to what the round still needs."""
+
+    def __init__(self, n_needed):
+        self.seen, self.rows, self.scores, self.n_needed = set(), [], [], n_needed
+
+    def consume(self, t, s):
+        new = 0
+        for r, v in zip(t.tolist(), s.tolist()):
+            if tuple(r) not in self.seen and len(self.rows) < self.n_needed:
+                self.seen.add(tuple(r))
+                self.rows.append(r)
+                self.scores.append(v)
+                new += 1
+        return new
+
+
+def _thompson(world, rank, n_needed, max_draws):
+    import numpy as np
+    from sgpo_amd.dist import thompson_round
+    rng = np.random.RandomState(11)                      # util/seed.py: every rank seeds numpy alike
+    store = _Store(n_needed)
+    n_new, k = thompson_round(_stub_draw, store.consume, n_needed, max_draws, lambda: int(rng.randint(0, 10)), seed=3,
+                              rank=rank, world=world)
+    return n_new, k, store.rows, store.scores
+
+
+def _worker_cells(rank, world, port, q):
+    from sgpo_amd.dist import run_cells, share_members
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        cells = [(c, r, 3 + (r % 2)) for r in range(3) for c in (0.1, 1.0, 10.0)]       # 9 cells, ragged batch sizes
+        got = run_cells(cells, _stub_cell, seed=42)
+        want = run_cells(cells, _stub_cell, seed=42, rank=0, world=1)
+        ok = len(got) == len(cells) and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got, want))
+        # ensemble weights trained on different ranks reach every rank
+        local = {m: torch.full((5,), float(m)) for m in range(5) if m % world == rank}
+        blobs = share_members(local, 5)
+        ok = ok and all(torch.equal(b, torch.full((5,), float(m))) for m, b in enumerate(blobs))
+        # Thompson round: same accepted rows, same stopping draw as the one-rank loop
+        for n_needed, max_draws in ((20, 50), (1000, 7), (3, 50)):
+            ok = ok and _thompson(world, rank, n_needed, max_draws) == _thompson(1, 0, n_needed, max_draws)
+        q.put((rank, ok))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_cells_and_thompson_draws_world2_equal_the_single_rank_run():
+    world, port = 2, _free_port()
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker_cells, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok in res), res
+
+
+def test_item_seed_and_deal():
+    from sgpo_amd.dist import deal, item_seed
+    assert sorted(sum((deal(10, r, 4) for r in range(4)), [])) == list(range(10))
+    assert deal(2, 3, 4) == []
+    keys = {item_seed(42, i) for i in range(1000)} | {item_seed(43, i) for i in range(1000)}
+    assert len(keys) == 2000 and all(0 <= k < 2 ** 64 for k in keys)

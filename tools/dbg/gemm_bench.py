@@ -12,7 +12,8 @@ g = torch.Generator().manual_seed(1)
 x = torch.randint(0, 31, (B, 119), generator=g).cuda()
 sigma = (torch.rand(B, generator=g) * 3).cuda()
 for dbg in os.environ.get('DBG_LIST', '0').split(','):
-    os.environ['SGPO_GEMM_DBG'] = dbg
+    os.environ['SGPO_GEMM_DBG'] = dbg.split(':')[0]
+    os.environ['SGPO_GEMM_STAGGER_US'] = dbg.split(':')[1] if ':' in dbg else '0'   # 'bits:us' = ablation bits : start stagger
     net.forward(x, sigma)
     torch.cuda.synchronize()
     L.check(lib.sgpo_prof_enable(1, 4096), 'prof')
