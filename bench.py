@@ -12,6 +12,11 @@ function scores over RCCL, as SURVEY.md section 8(e) lays out.
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
+`--config {2,3,4,5}` selects another BASELINE configuration for the same JSON line (2 is the default and the
+driver's headline): 3 = D3PM + daps_discrete on TrpB, 2048 sequences per GPU (a bench step is ONE of the run's 50
+identical annealing steps, `value` is scaled to whole runs); 4 = MDLM + NOS_discrete on TrpB, one (strength, repeat)
+cell of 200 sequences per GPU and step; 5 = Thompson draws of 10 sequences, one ensemble member per GPU and step.
+
 Prints ONE JSON line (rank 0) with `roofline` (dominant kernel, HIP-event timed on the launch
 stream during the timed steps) and `cpu_baseline` (the CPU oracle on a bounded sample).
 """
@@ -113,16 +118,296 @@ def gemm_algorithmic_bytes(kind, batch, L=119, h=512, ff=2048):
         return M * h * 2 + h * ff * 2 + M * ff * 2
     return None
 
+# ---------------------------------------------------------------------------------------------------------------
+# The other BASELINE configurations through the same contract (`--config 3|4|5`).  Config 2 above stays the default.
+TRPB_RES = [117, 118, 119, 162, 166, 182, 183, 184, 185, 186, 227, 228, 230, 231, 301]
+L_TRPB = 389
+
+
+def _trpb_parent():
+    g = torch.Generator().manual_seed(0)
+    return ''.join(ALPHABET[int(t)] for t in torch.randint(0, 20, (L_TRPB,), generator=g))
+
+
+class _Config3:
+    """D3PM (ByteNet 16 x d1024) + daps_discrete on TrpB; the batch shards over ranks (2048 sequences per GPU).  A run is
+    50 identical annealing steps (19 denoiser forwards + posteriors, 1000 MH proposals, q_sample); ONE of them is a bench
+    step and `value` credits batch / 50 sequences per step."""
+    default_batch, steps_per_run = 2048, 50
+
+    def __init__(self, device, batch, rank, world):
+        import sgpo_amd
+        sgpo_amd.install_dropin()
+        from models.d3pm import D3PM
+        from problem.protein import ProteinPredictor
+        from sampling.daps import DAPS
+        from sgpo_amd import weights as W
+        self.B, self.rank, self.world = batch, rank, world
+        self.bn_sd = W.bytenet_synthetic_state(seed=0)
+        self.net = D3PM('synthetic', L_TRPB, device=device, state_dict=self.bn_sd)
+        dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=L_TRPB, full_seq=_trpb_parent(), residues=TRPB_RES)
+        self.pred = ProteinPredictor(dc, dict(hidden_dim=64), device=device)
+        self.msd = W.mlp_synthetic_state(seed=1, n_residues=len(TRPB_RES))
+        self.pred.model.load_state_dict(self.msd)
+        self.pred.eval()
+        self.algo = DAPS(self.net, forward_op=self.pred, num_steps=50, ode_steps=20, mh_steps=1000, alpha=128., beta=1000,
+                         data_config=dc, device=device)
+        self.xt = None
+
+    def step(self, i):
+        """Annealing step i (mod 49, so that q_sample is always part of it) of the 50-step schedule on the running state."""
+        a, net = self.algo, self.net
+        if self.xt is None or i < 0:
+            net.reseed(seed=7, row_offset=self.rank * self.B)
+            self.xt = net.get_start(self.B)
+        k = i % (a.num_steps - 1)
+        t_now = a.time_steps[k]
+        x0 = a.uncond_sample(net, self.xt, t_now, False)
+        x0 = a.metropolis_hasting(x0, a.forward_op, None, a._sigma_at(t_now), steps=a.mh_steps, alpha=a.alpha)
+        self.xt = net.q_sample(x0, a.time_steps[k + 1].repeat(self.B))
+        return x0, self.pred.log_likelihood(x0)
+
+    def units(self):
+        return self.world * self.B / self.steps_per_run
+
+    def n_launches(self, steps):
+        return steps * 3000 + 64
+
+    def describe(self):
+        return {'workload': 'D3PM (ByteNet 16 x d1024/h512, k5) + daps_discrete on TrpB, L=389, 15 residues, %d sequences per GPU; '
+                            'one bench step = one of the 50 annealing steps of a run (19 denoiser forwards + fp64 posteriors, 1000 MH '
+                            'proposals, q_sample); value = sequences per second of whole 50-step runs at that step time' % self.B,
+                'denoiser': 'ByteNetLMTime restated (third party, parity unpinned), bf16 MFMA / fp32 accumulate',
+                'global_batch': self.world * self.B, 'parallelism': f'dp{self.world} (batch rows sharded + all-gather of tokens/scores)'}
+
+    def cpu_baseline(self):
+        sys.path.insert(0, os.path.join(ROOT, 'tools'))
+        import bench_daps
+        return bench_daps.cpu_baseline(self.bn_sd, self.msd)
+
+
+class _Config4:
+    """MDLM + NOS_discrete on TrpB (pareto.py sweep): one (guidance strength, repeat) cell of 200 sequences per GPU and
+    bench step; cells are dealt to the ranks and gathered once (sgpo_amd.dist.run_cells)."""
+    default_batch = 200
+    COEFS = [0.1, 1.0, 10.0, 100.0, 200.0]
+
+    def __init__(self, device, batch, rank, world):
+        import sgpo_amd
+        sgpo_amd.install_dropin()
+        from models.mdlm import MDLM
+        from problem.protein_nos import NOSHead
+        from sampling.NOS import NOS
+        from sgpo_amd import weights as W
+        self.B, self.rank, self.world, self.device = batch, rank, world, device
+        cfg = dict(diffusion='absorbing_state', parameterization='subs', time_conditioning=False,
+                   model=dict(hidden_size=512, cond_dim=128, n_blocks=8, n_heads=8, length=1024))
+        self.sd = W.dit_synthetic_state(seed=0)
+        self.net = MDLM('synthetic', cfg, None, num_steps=T_STEPS, seq_len=L_TRPB, device=device, state_dict=self.sd)
+        dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=L_TRPB, full_seq=_trpb_parent(), residues=TRPB_RES)
+        torch.manual_seed(1)
+        self.head = NOSHead(512).to(device).eval()
+        self.algo = NOS(self.net, dc, forward_op=self.head, num_nos_steps=5, nos_step_size=0.5, nos_stability_coef=0.1, device=device)
+
+    def _cell(self, cell, key):
+        coef, _rep = cell
+        self.algo.nos_stability_coef = coef
+        self.net.reseed(seed=key, row_offset=0)
+        x = self.algo.inference(num_samples=self.B, verbose=False)
+        return x, None
+
+    def step(self, i):
+        from sgpo_amd.dist import run_cells
+        cells = [(self.COEFS[(i * self.world + r) % len(self.COEFS)], (i * self.world + r) // len(self.COEFS)) for r in range(self.world)]
+        out = run_cells(cells, self._cell, seed=42 + i, rank=self.rank, world=self.world)
+        return out[0][0], None
+
+    def units(self):
+        return self.world * self.B
+
+    def n_launches(self, steps):
+        return steps * (T_STEPS - 1) * 80 + 64
+
+    def describe(self):
+        return {'workload': 'MDLM + NOS_discrete on TrpB, L=389, 127 reverse steps x (1 denoiser forward + 5 hidden-state optimisation '
+                            'steps of size 0.5), %d sequences per (guidance strength, repeat) cell, one cell per GPU and bench step, '
+                            'strengths %s' % (self.B, self.COEFS),
+                'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate', 'global_batch': self.world * self.B,
+                'parallelism': f'{self.world} cells at a time (independent sampler calls + one all-gather of tokens)'}
+
+    def cpu_baseline(self, n_seq=2, n_steps=3):
+        from oracle import nos as onos
+        cores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(cores)
+        g = torch.Generator().manual_seed(5)
+        x = torch.full((n_seq, L_TRPB), 28, dtype=torch.int64)
+        w, b = torch.randn(1, 512, generator=g) * 0.5, torch.randn(1, generator=g)
+        t0 = time.perf_counter()
+        for k in range(n_steps):
+            u = torch.rand(n_seq, L_TRPB, 31, generator=g)
+            x, _, _ = onos.nos_denoise(self.sd, w, b, x, T_STEPS - 1 - k, T_STEPS, 28, 5, 0.5, 0.1, u)
+            x = x.clone()
+            x[:, ::2] = 28                  # keep half the positions masked so every step does the masked-row work
+        dt = time.perf_counter() - t0
+        per_seq = dt / n_seq * (T_STEPS - 1) / n_steps
+        return dict(value=1.0 / per_seq, unit='sequences/s', cores=cores, kind='port',
+                    sample=f'{n_seq} sequences x {n_steps} of 127 NOS reverse steps (autograd + Adagrad oracle, torch-CPU fp32), '
+                           f'{dt:.1f} s measured, scaled linearly to 127 steps')
+
+
+class _Config5(_Config4):
+    """iterativeBO.py Thompson sampling: every GPU draws an ensemble member and samples 10 guided sequences with it
+    (MDLM + cls_guidance_discrete on CreiLOV); a bench step is one wave of `world` draws, gathered once."""
+    default_batch = 10
+
+    def __init__(self, device, batch, rank, world):
+        self.B, self.rank, self.world = batch, rank, world
+        self.net, pred0, self.algo, self.sd, self.msd = build(device, batch)
+        from problem.protein import ProteinPredictor
+        from sgpo_amd import weights as W
+        dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=119, full_seq=CREILOV, residues=None)
+        self.members = []
+        for m in range(10):
+            p = ProteinPredictor(dc, dict(hidden_dim=64), device=device)
+            p.model.load_state_dict(W.mlp_synthetic_state(seed=100 + m, n_residues=119))
+            self.members.append(p.eval())
+        import numpy as np
+        self.rng = np.random.RandomState(42)
+
+    def _draw(self, member, key):
+        clf = self.members[member]
+        self.algo.update_model(clf)
+        self.net.reseed(seed=key, row_offset=0)
+        x = self.algo.inference(num_samples=self.B)
+        return x, clf.log_likelihood(x)
+
+    def step(self, i):
+        from sgpo_amd.dist import thompson_round
+        got = []
+        thompson_round(self._draw, lambda t, s: (got.append((t, s)) or t.shape[0]), n_needed=10 ** 9, max_draws=self.world,
+                       pick_member=lambda: int(self.rng.randint(0, 10)), seed=1000 + i, rank=self.rank, world=self.world)
+        return got[0]
+
+    def units(self):
+        return self.world * self.B
+
+    def describe(self):
+        return {'workload': 'MDLM + cls_guidance_discrete (temperature 0.064) on CreiLOV, L=119, 127 reverse steps, Thompson draws of '
+                            '%d sequences, each guided by one of 10 value-function members; one draw per GPU and bench step '
+                            '(ensemble training is outside the timed region: tools/bench_bo.py times a whole round)' % self.B,
+                'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate', 'global_batch': self.world * self.B,
+                'parallelism': f'{self.world} draws at a time (independent sampler calls + one all-gather of tokens/scores)'}
+
+    def cpu_baseline(self):
+        return cpu_baseline(self.sd, self.msd, n_seq=10, n_steps=24)
+
+
+def main_other(a):
+    """Configs 3 / 4 / 5 through the bench contract: W warm-up steps, K timed steps between barrier + synchronize, max over
+    ranks, one JSON line from rank 0 with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`."""
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1 and a.gpus > 1:
+        raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
+    device = f'cuda:{local_rank}'
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group('nccl', device_id=torch.device(device))
+    from sgpo_amd import _lib as L
+    cls = {3: _Config3, 4: _Config4, 5: _Config5}[a.config]
+    wl = cls(device, a.batch or cls.default_batch, rank, world)
+    lib = L.load()
+
+    def one_step(i):
+        x, sc = wl.step(i)
+        if world > 1 and a.config == 3:          # batch rows sharded: the all-gather of tokens (uint8) and scores
+            B = x.shape[0]
+            all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
+            all_s = torch.empty(world * B, dtype=torch.float32, device=device)
+            dist.all_gather_into_tensor(all_t, x.to(torch.uint8))
+            dist.all_gather_into_tensor(all_s, sc.to(torch.float32))
+            return all_t, all_s
+        return x, sc
+
+    def sync():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(a.warmup):
+        one_step(-1 - i)
+    sync()
+    if not a.no_prof:
+        L.check(lib.sgpo_prof_enable(1, wl.n_launches(a.steps)), 'prof_enable')
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        out = one_step(i)
+    sync()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    roof, kernels = None, {}
+    if not a.no_prof:
+        n = L.PROF_KINDS
+        ms, cnt, work = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+        L.check(lib.sgpo_prof_read(n, ms, cnt, work), 'prof_read')
+        lib.sgpo_prof_enable(0, 0)
+        tot = sum(ms)
+        for k in range(n):
+            if cnt[k]:
+                kernels[lib.sgpo_prof_kind_name(k).decode()] = dict(total_ms=round(ms[k], 3), launches=int(cnt[k]),
+                                                                    avg_us=round(1e3 * ms[k] / cnt[k], 2), share=round(ms[k] / tot, 4),
+                                                                    work_per_launch=work[k] / cnt[k])
+        dom = max(range(n), key=lambda k: ms[k])
+        name = lib.sgpo_prof_kind_name(dom).decode()
+        per_launch, avg_s = work[dom] / cnt[dom], ms[dom] / cnt[dom] * 1e-3
+        if name.startswith(('gemm', 'attention')):      # work = flops (2 M N K); the fused GEMMs of these shapes are MFMA-side
+            ach = per_launch / avg_s / 1e12
+            roof = dict(bound='mfma', kernel=name, achieved=round(ach, 2), peak=MFMA_BF16_PEAK_TFLOPS, unit='TFLOP/s',
+                        frac=round(ach / MFMA_BF16_PEAK_TFLOPS, 4), traffic=None, avg_launch_us=round(avg_s * 1e6, 2),
+                        flops_per_launch=per_launch)
+        else:                                           # work = algorithmic bytes
+            ach = per_launch / avg_s / 1e9
+            roof = dict(bound='hbm', kernel=name, achieved=round(ach, 1), peak=HBM_PEAK_GBS, unit='GB/s',
+                        frac=round(ach / HBM_PEAK_GBS, 4), traffic=None, avg_launch_us=round(avg_s * 1e6, 2),
+                        bytes_per_launch=per_launch)
+        gf = sum(work[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
+        gt = sum(ms[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
+        if gt > 0:
+            roof['denoiser_tflops'] = round(gf / (gt * 1e-3) / 1e12, 2)
+        roof['gpu_busy_frac'] = round(tot * 1e-3 / dt, 4)
+    if rank == 0:
+        cpu = wl.cpu_baseline() if (not a.no_cpu_baseline and world == 1) else None
+        cfg = wl.describe()
+        cfg['baseline_config'] = a.config
+        print(json.dumps({
+            'metric': 'guided sequences/sec (whole node)', 'value': round(wl.units() * a.steps / dt, 3), 'unit': 'sequences/s',
+            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'config': cfg,
+            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'checksum': int(out[0].long().sum())}))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--batch', type=int, default=4096, help='sequences per GPU per step')
+    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5], help='BASELINE configuration (2 = headline)')
+    ap.add_argument('--batch', type=int, default=None, help='sequences per GPU per step (default: the configuration\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
     a = ap.parse_args()
+    if a.config != 2:
+        return main_other(a)
+    a.batch = a.batch or 4096
 
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
