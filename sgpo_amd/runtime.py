@@ -67,8 +67,7 @@ class DitDenoiser:
         self.vocab, self.hidden = d['vocab'], d['hidden']
         self.cfg = L.DitConfig(d['vocab'], d['hidden'], d['cond_dim'], d['freq_dim'], d['n_blocks'], d['n_heads'],
                                d['mlp_hidden'], max_len)
-        keys = DIT_ORDER_HEAD + [f'blocks.{i}.{k}' for i in range(d['n_blocks']) for k in DIT_ORDER_BLOCK] + DIT_ORDER_TAIL
-        blob = _blob(state_dict, keys, self.device)
+        blob = _blob(state_dict, dit_keys(d['n_blocks']), self.device)
         n = self.lib.sgpo_dit_param_count(C.byref(self.cfg))
         if blob.numel() != n:
             raise L.SgpoError(f'DiT state dict has {blob.numel()} parameters, library expects {n}')
@@ -534,6 +533,20 @@ BN_LAYER_ORDER = ['sequence1.0.weight', 'sequence1.0.bias', 'sequence1.2.conv.we
                   'sequence2.0.bias', 'sequence2.2.conv.weight', 'sequence2.2.conv.bias']
 
 
+def bytenet_keys(n_layers):
+    """State-dict keys of ByteNetLMTime in blob order (the `network.` prefix of the Lightning checkpoint stripped:
+    models/pretraining/pretrained.py:10-15, d3pm_evodiff.py:45,54).  Other entries of a checkpoint (buffers such as the
+    timestep encoding table, optimizer or EMA state) are not read."""
+    keys = ['embedder.embedder.weight', 'embedder.up_embedder.conv.weight', 'embedder.up_embedder.conv.bias']
+    keys += [f'embedder.layers.{n}.{k}' for n in range(n_layers) for k in BN_LAYER_ORDER]
+    return keys + ['decoder.conv.weight', 'decoder.conv.bias']
+
+
+def dit_keys(n_blocks):
+    """State-dict keys of the DiT backbone in blob order (`backbone.` prefix stripped)."""
+    return DIT_ORDER_HEAD + [f'blocks.{i}.{k}' for i in range(n_blocks) for k in DIT_ORDER_BLOCK] + DIT_ORDER_TAIL
+
+
 class BytenetDenoiser:
     """ByteNetLMTime forward on the GPU (third-party architecture restated; parity unpinned)."""
 
@@ -547,10 +560,7 @@ class BytenetDenoiser:
         n_layers = 1 + max(int(k.split('.')[2]) for k in sd if k.startswith('embedder.layers.'))
         self.n_tokens, self.d_model = n_tokens, d_model
         self.cfg = L.BytenetConfig(n_tokens, d_emb, d_model, d_h, n_layers, ks, r)
-        keys = ['embedder.embedder.weight', 'embedder.up_embedder.conv.weight', 'embedder.up_embedder.conv.bias']
-        keys += [f'embedder.layers.{n}.{k}' for n in range(n_layers) for k in BN_LAYER_ORDER]
-        keys += ['decoder.conv.weight', 'decoder.conv.bias']
-        blob = _blob(sd, keys, self.device)
+        blob = _blob(sd, bytenet_keys(n_layers), self.device)
         n = self.lib.sgpo_bytenet_param_count(C.byref(self.cfg))
         if blob.numel() != n:
             raise L.SgpoError(f'ByteNet state dict has {blob.numel()} parameters, library expects {n}')

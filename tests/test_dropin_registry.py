@@ -77,3 +77,47 @@ def test_checkpoint_importer_uses_the_non_executing_loader(tmp_path, monkeypatch
     with pytest.raises(KeyError):
         torch.save({'state_dict': {'other.w': torch.ones(3)}}, p)
         W.load_lightning_state(p, 'backbone.')
+
+
+def test_importers_read_the_reference_checkpoint_key_layout(tmp_path, monkeypatch):
+    """f-4: `checkpoints/<name>/best_model.ckpt` as Lightning writes it for the two denoisers -- `backbone.*` + `noise.*`
+    (+ EMA and optimizer entries) for MDLM (mdlm_diffusion.py:232-245), `network.embedder.*` / `network.decoder.*` for the
+    EvoDiff ByteNet (models/pretraining/pretrained.py:10-15, d3pm_evodiff.py:45,54).  Synthetic files with that layout,
+    extra entries included, load through the drop-in loaders into exactly the tensors the library's blobs are cut from."""
+    import torch
+    sgpo_amd.install_dropin()
+    from models import d3pm as dd
+    from models import mdlm as dm
+    from sgpo_amd import runtime as rt
+    from sgpo_amd import weights as W
+    monkeypatch.chdir(tmp_path)
+    monkeypatch.delenv('SGPO_SYNTHETIC_WEIGHTS', raising=False)
+    # ---- ByteNet (small dims keep the file small; the key layout does not depend on them)
+    bn = W.bytenet_synthetic_state(seed=3, d_model=64, n_layers=3)
+    ck = {'network.' + k: v for k, v in bn.items()}
+    ck['network.embedder.time_encoding.pe'] = torch.zeros(500, 8)         # a buffer the blob does not take
+    ck['loss_func.weight'] = torch.ones(3)
+    (tmp_path / 'checkpoints' / 'd3pm_finetune' / 'TrpB').mkdir(parents=True)
+    torch.save({'state_dict': ck, 'epoch': 3, 'global_step': 100, 'pytorch-lightning_version': '2.0.0'},
+               tmp_path / 'checkpoints' / 'd3pm_finetune' / 'TrpB' / 'best_model.ckpt')
+    sd = dd._load_bytenet_state('d3pm_finetune/TrpB')                       # configs: pretrained_ckpt d3pm_finetune/TrpB
+    keys = rt.bytenet_keys(3)
+    assert all(k in sd for k in keys) and 'loss_func.weight' not in sd
+    assert all(torch.equal(sd[k], bn[k]) for k in keys)
+    assert sum(sd[k].numel() for k in keys) == sum(v.numel() for v in bn.values())
+    # ---- MDLM / DiT
+    dims = dict(hidden=128, cond_dim=32, n_blocks=2, n_heads=2)
+    dit = W.dit_synthetic_state(seed=5, vocab=31, **dims)
+    ck = {'backbone.' + k: v for k, v in dit.items()}
+    ck['noise.eps'] = torch.tensor(1e-3)
+    ck['ema.shadow_params.0'] = torch.zeros(4)
+    (tmp_path / 'checkpoints' / 'mdlm' / 'CreiLOV').mkdir(parents=True)
+    torch.save({'state_dict': ck, 'ema': {'decay': 0.9999, 'num_updates': 5}, 'epoch': 1},
+               tmp_path / 'checkpoints' / 'mdlm' / 'CreiLOV' / 'best_model.ckpt')
+    sd = dm._load_dit_state('mdlm/CreiLOV', {})
+    assert W.dit_dims(sd) == dict(vocab=31, hidden=128, cond_dim=32, freq_dim=256, n_blocks=2, n_heads=2, mlp_hidden=512)
+    assert all(torch.equal(sd[k], dit[k]) for k in rt.dit_keys(2)) and not any(k.startswith(('noise', 'ema')) for k in sd)
+    # a missing checkpoint names the way out instead of falling back silently
+    import pytest
+    with pytest.raises(FileNotFoundError, match='SGPO_SYNTHETIC_WEIGHTS'):
+        dd._load_bytenet_state('d3pm_finetune/CreiLOV')
