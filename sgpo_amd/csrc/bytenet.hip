@@ -113,8 +113,8 @@ __global__ __launch_bounds__(256) void ln_gelu_kernel(const float* __restrict__ 
     float o2 = gelu_erf((v[i * 4 + 2] - mean) * rstd * ww.z + bb.z);
     float o3 = gelu_erf((v[i * 4 + 3] - mean) * rstd * ww.w + bb.w);
     uint2 pk;
-    pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-    pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+    pk.x = pack_bf16x2(o0, o1);
+    pk.y = pack_bf16x2(o2, o3);
     *reinterpret_cast<uint2*>(out + (size_t)row * H + col) = pk;
   }
 }

@@ -39,6 +39,14 @@ __device__ __forceinline__ bf16_t f2bf(float f) {
   __bf16 b = (__bf16)f;
   return *reinterpret_cast<bf16_t*>(&b);
 }
+// two f32 -> one dword of two bf16 (lo = a, hi = b) in ONE v_cvt_pk_bf16_f32; the same round-to-nearest-even values as
+// two f2bf (written as `f2bf(a) | f2bf(b) << 16` the compiler emits two conversions, a shift and an or)
+typedef __bf16 bf16x2_vt __attribute__((ext_vector_type(2)));
+typedef float f32x2_vt __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t pack_bf16x2(float a, float b) {
+  const bf16x2_vt v = __builtin_convertvector(f32x2_vt{a, b}, bf16x2_vt);
+  return *reinterpret_cast<const uint32_t*>(&v);
+}
 __device__ __forceinline__ float bf2f(bf16_t h) {
   return __uint_as_float(((uint32_t)h) << 16);
 }

@@ -125,8 +125,8 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
     float o2 = (v[i * 4 + 2] - mean) * rstd * ww.z * (1.f + c4.z) + s4.z;
     float o3 = (v[i * 4 + 3] - mean) * rstd * ww.w * (1.f + c4.w) + s4.w;
     uint2 pk;
-    pk.x = (uint32_t)f2bf(o0) | ((uint32_t)f2bf(o1) << 16);
-    pk.y = (uint32_t)f2bf(o2) | ((uint32_t)f2bf(o3) << 16);
+    pk.x = pack_bf16x2(o0, o1);
+    pk.y = pack_bf16x2(o2, o3);
     *reinterpret_cast<uint2*>(out + (size_t)row * H + col) = pk;
   }
 }
@@ -333,10 +333,10 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : NW == 8 ? 2 : 1) void attent
     uint32_t w0[8], w1[8];   // w[2g], w[2g+1]: this lane's half of chunk g
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      w0[2 * g] = (uint32_t)f2bf(o0[g * 4 + 0] * inv) | ((uint32_t)f2bf(o0[g * 4 + 1] * inv) << 16);
-      w0[2 * g + 1] = (uint32_t)f2bf(o0[g * 4 + 2] * inv) | ((uint32_t)f2bf(o0[g * 4 + 3] * inv) << 16);
-      w1[2 * g] = (uint32_t)f2bf(o1[g * 4 + 0] * inv) | ((uint32_t)f2bf(o1[g * 4 + 1] * inv) << 16);
-      w1[2 * g + 1] = (uint32_t)f2bf(o1[g * 4 + 2] * inv) | ((uint32_t)f2bf(o1[g * 4 + 3] * inv) << 16);
+      w0[2 * g] = pack_bf16x2(o0[g * 4 + 0] * inv, o0[g * 4 + 1] * inv);
+      w0[2 * g + 1] = pack_bf16x2(o0[g * 4 + 2] * inv, o0[g * 4 + 3] * inv);
+      w1[2 * g] = pack_bf16x2(o1[g * 4 + 0] * inv, o1[g * 4 + 1] * inv);
+      w1[2 * g + 1] = pack_bf16x2(o1[g * 4 + 2] * inv, o1[g * 4 + 3] * inv);
     }
     // swap(X = half of chunk 2k, Y = half of chunk 2k+1): lanes 32..63 of X <-> lanes 0..31 of Y.  Afterwards the
     // lower lanes hold chunk 2k as (X, Y) and the upper lanes chunk 2k+1 as (X, Y).

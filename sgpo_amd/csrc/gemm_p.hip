@@ -74,8 +74,8 @@ __device__ __forceinline__ void wait_vm() {
 
 __device__ __forceinline__ u32x2_t pack4(float a, float b, float c, float d) {
   u32x2_t r;
-  r.x = (uint32_t)f2bf(a) | ((uint32_t)f2bf(b) << 16);
-  r.y = (uint32_t)f2bf(c) | ((uint32_t)f2bf(d) << 16);
+  r.x = pack_bf16x2(a, b);
+  r.y = pack_bf16x2(c, d);
   return r;
 }
 
@@ -318,6 +318,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     for (int i = 0; i < 4; ++i) {
       u32x4_t v = o[i];
       if (i & 1) v = u32x4_t{o[i].z, o[i].w, o[i].x, o[i].y};   // rows with bit 3 set hold swapped halves
+      if (ABL(16)) { asm volatile("" ::"v"(v)); continue; }   // diagnostic: no output stores
+      if (ABL(128)) { if (FULL || m_blk + i * 8 + r8 < p.M) *reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc) = v; continue; }   // diagnostic: plain stores
       if (FULL || m_blk + i * 8 + r8 < p.M)
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc));   // streamed once: keep L2 for the operand panels
     }
@@ -339,7 +341,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       for (int i = 0; i < 8; ++i) {
         size_t ro = (size_t)(i * 4) * p.ldc;
         if (!FULL && m_blk + i * 4 + r4 > p.M - 1) ro = 0;   // any valid row: the value is not stored
-        xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xp + ro));
+        if (ABL(32)) xr[i] = f32x4_t{0.f, 0.f, 0.f, 0.f};   // diagnostic: no residual loads
+        else xr[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xp + ro));
       }
     }
     const uint32_t k0 = r4 * 256 + ((c16 ^ r4) << 4), k1 = r4 * 256 + ((c16 ^ (r4 + 4)) << 4);
@@ -356,6 +359,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
           const f32x4_t x4 = xr[i];
           v = f32x4_t{rn_add(x4.x, o[j].x), rn_add(x4.y, o[j].y), rn_add(x4.z, o[j].z), rn_add(x4.w, o[j].w)};
         }
+        if (ABL(16)) { asm volatile("" ::"v"(v)); continue; }   // diagnostic: no output stores
+        if (ABL(128)) { if (FULL || m_blk + i * 4 + r4 < p.M) *reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc) = v; continue; }   // diagnostic: plain stores
         if (FULL || m_blk + i * 4 + r4 < p.M) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc));
       }
     }
@@ -486,7 +491,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
             const f32x4_t b4 = bb[nt][g];
             float v[4] = {acc[nt][mt][4 * g + 0] + b4.x, acc[nt][mt][4 * g + 1] + b4.y,
                           acc[nt][mt][4 * g + 2] + b4.z, acc[nt][mt][4 * g + 3] + b4.w};
-            if constexpr (EPI == EPI_BIAS_GELU) {
+            if constexpr (EPI == EPI_BIAS_GELU) if (!ABL(64)) {   // diagnostic bit 64: no GELU arithmetic
               const f32x2_t g0 = epi_gelu_tanh2(f32x2_t{v[0], v[1]}), g1 = epi_gelu_tanh2(f32x2_t{v[2], v[3]});
               v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
             }
