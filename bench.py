@@ -302,6 +302,41 @@ class _Config5(_Config4):
         return cpu_baseline(self.sd, self.msd, n_seq=10, n_steps=24)
 
 
+def _dist_init(world, local_rank):
+    """One process per GPU over RCCL (`nccl`).  SGPO_BENCH_BACKEND=gloo is the rehearsal of the N > 1 control flow on a box
+    with fewer GPUs than ranks (RCCL refuses two ranks on one device): ranks share the GPUs round-robin and the gathers are
+    staged through the host; it is never used for a reported number."""
+    backend = os.environ.get('SGPO_BENCH_BACKEND', 'nccl')
+    index = local_rank if backend == 'nccl' else local_rank % max(torch.cuda.device_count(), 1)
+    device = f'cuda:{index}'
+    torch.cuda.set_device(index)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        if backend == 'nccl':
+            dist.init_process_group('nccl', device_id=torch.device(device))
+        else:
+            dist.init_process_group(backend)
+    return dist, device, backend
+
+
+def _all_gather(dist, backend, out, x):
+    x = x.detach()
+    if backend == 'nccl':
+        dist.all_gather_into_tensor(out, x)
+    else:
+        host = torch.empty(out.shape, dtype=out.dtype)
+        with torch.no_grad():
+            dist.all_gather_into_tensor(host, x.cpu())
+        out.copy_(host)
+
+
+def _max_over_ranks(dist, backend, dt, device):
+    tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    return float(tt.item())
+
+
 def main_other(a):
     """Configs 3 / 4 / 5 through the bench contract: W warm-up steps, K timed steps between barrier + synchronize, max over
     ranks, one JSON line from rank 0 with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`."""
@@ -310,12 +345,7 @@ def main_other(a):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world == 1 and a.gpus > 1:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-    device = f'cuda:{local_rank}'
-    torch.cuda.set_device(local_rank)
-    dist = None
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device(device))
+    dist, device, backend = _dist_init(world, local_rank)
     from sgpo_amd import _lib as L
     cls = {3: _Config3, 4: _Config4, 5: _Config5}[a.config]
     wl = cls(device, a.batch or cls.default_batch, rank, world)
@@ -327,8 +357,8 @@ def main_other(a):
             B = x.shape[0]
             all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
             all_s = torch.empty(world * B, dtype=torch.float32, device=device)
-            dist.all_gather_into_tensor(all_t, x.to(torch.uint8))
-            dist.all_gather_into_tensor(all_s, sc.to(torch.float32))
+            _all_gather(dist, backend, all_t, x.to(torch.uint8))
+            _all_gather(dist, backend, all_s, sc.to(torch.float32))
             return all_t, all_s
         return x, sc
 
@@ -348,9 +378,7 @@ def main_other(a):
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = _max_over_ranks(dist, backend, dt, device)
     roof, kernels = None, {}
     if not a.no_prof:
         n = L.PROF_KINDS
@@ -415,12 +443,7 @@ def main():
     if world != a.gpus:
         if world == 1 and a.gpus > 1:
             raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
-    dist = None
-    device = f'cuda:{local_rank}'
-    torch.cuda.set_device(local_rank)
-    if world > 1:
-        import torch.distributed as dist
-        dist.init_process_group('nccl', device_id=torch.device(device))
+    dist, device, backend = _dist_init(world, local_rank)
 
     from sgpo_amd import _lib as L
     net, pred, algo, sd, msd = build(device, a.batch)
@@ -436,8 +459,8 @@ def main():
             toks = x.to(torch.uint8)
             all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
             all_s = torch.empty(world * B, dtype=torch.float32, device=device)
-            dist.all_gather_into_tensor(all_t, toks)
-            dist.all_gather_into_tensor(all_s, score)
+            _all_gather(dist, backend, all_t, toks)
+            _all_gather(dist, backend, all_s, score)
             return all_t, all_s
         return x, score
 
@@ -459,9 +482,7 @@ def main():
     sync()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt.item())
+        dt = _max_over_ranks(dist, backend, dt, device)
 
     roof = None
     kernels = {}

@@ -41,6 +41,15 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
 struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NST = 3, PH = 2; };
+#ifdef SGPO_GEMM_ABLATE
+// Diagnostic build only: a 128 x 512 tile (whole rows of the hidden width 512 in one workgroup), K loop only -- the two
+// slots fill the LDS, so there is no bias table and no epilogue.  It prices the operand traffic of the full-row tile
+// that a fused residual + LayerNorm epilogue would need (SGPO_GEMM_TILE=r).
+struct CfgRow { static constexpr int WM = 1, WN = 8, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
+template <typename C> struct is_row_cfg : std::is_same<C, CfgRow> {};
+#else
+template <typename C> struct is_row_cfg : std::false_type {};
+#endif
 
 enum { PF_EXACT = 1 };
 #define LDS_MAX_BYTES 163840
@@ -153,7 +162,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
   static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
-  static_assert(!STAGED32 || (A_PW >= 4 && B_PW >= 4), "fp32 output staging: 32 x 64 block = two 4-KiB halves");
+  static_assert(!STAGED32 || (A_PW >= 4 && B_PW >= 4) || is_row_cfg<CFG>::value, "fp32 output staging: 32 x 64 block = two 4-KiB halves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -194,7 +203,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   };
 
   // ---- aux tables -> LDS (once per launch; the only ordinary loads outside RES / fp32-out epilogues)
-  if constexpr (!F32OUT || F32ST) {
+  if constexpr ((!F32OUT || F32ST) && !is_row_cfg<CFG>::value) {
     if constexpr (EPI == EPI_QKV_ROPE) {
       if constexpr (ROPE_LDS) {
         const int n = p.L * (p.head_dim / 2);
@@ -721,6 +730,7 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   } else if (!F32OUT || CFG::MT * CFG::NT * 4 > 16) {
     aux = (size_t)q.N * sizeof(float);
   }
+  if (is_row_cfg<CFG>::value) aux = 0;
   if (RING + aux > LDS_MAX_BYTES) return SGPO_ERR_UNSUPPORTED;
   const int ntm = (q.M + BM - 1) / BM, ntn = (q.N + BN - 1) / BN;
   const int tiles = ntm * ntn;
@@ -763,7 +773,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   }
   if (tile_mode < 0) {
     const char* e = getenv("SGPO_GEMM_TILE");   // "s": always the 256x128 tile (A/B measurements)
-    tile_mode = (e && e[0] == 's') ? 1 : 0;
+    tile_mode = (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : 0;
   }
 #ifdef SGPO_GEMM_ABLATE
   { const char* e = getenv("SGPO_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
@@ -777,6 +787,10 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   const bool big = tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096 && p.ldc % 4 == 0;
   ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
+#ifdef SGPO_GEMM_ABLATE
+  if (tile_mode == 2 && epi == EPI_GATE_RES && p.N == 512)   // K loop of the full-row tile, no epilogue (bit 4 forced)
+    return launch_cfg<EPI_GATE_RES, CfgRow>(q, sg, zero16, n_cu, dbg | 4, stream);
+#endif
 #define LAUNCH_BOTH(E)                                                              \
   case E:                                                                           \
     if (big) rc = launch_cfg<E, CfgBig>(q, sg, zero16, n_cu, dbg, stream);          \

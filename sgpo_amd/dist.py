@@ -41,6 +41,7 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+@torch.no_grad()
 def gather_samples(tokens, scores=None, group=None):
     """All-gather per-rank samples.  tokens (b_r, L) integer -> (sum b_r, L) uint8 on every rank
     (tokens < 256: the 31-letter alphabet), scores (b_r,) fp32 -> (sum b_r,).  Ranks may hold
@@ -48,7 +49,11 @@ def gather_samples(tokens, scores=None, group=None):
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
         return tokens.to(torch.uint8), scores
     world = dist.get_world_size(group)
-    dev = tokens.device
+    home = tokens.device
+    # gloo carries host tensors only: a rehearsal of the N > 1 flow with GPU tensors stages the exchange through the host
+    dev = torch.device('cpu') if dist.get_backend(group) == 'gloo' else home
+    tokens = tokens.detach().to(dev)
+    scores = scores if scores is None else scores.detach().to(dev)
     n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=dev)
     counts = [torch.zeros_like(n) for _ in range(world)]
     dist.all_gather(counts, n, group=group)
@@ -60,14 +65,14 @@ def gather_samples(tokens, scores=None, group=None):
     all_t = torch.empty(world * mx, Lq, dtype=torch.uint8, device=dev)
     dist.all_gather_into_tensor(all_t, pad_t, group=group)
     keep = torch.cat([torch.arange(r * mx, r * mx + c, device=dev) for r, c in enumerate(counts)])
-    out_t = all_t[keep]
+    out_t = all_t[keep].to(home)
     out_s = None
     if scores is not None:
         pad_s = torch.zeros(mx, dtype=torch.float32, device=dev)
         pad_s[:scores.shape[0]] = scores.to(torch.float32)
         all_s = torch.empty(world * mx, dtype=torch.float32, device=dev)
         dist.all_gather_into_tensor(all_s, pad_s, group=group)
-        out_s = all_s[keep]
+        out_s = all_s[keep].to(home)
     return out_t, out_s
 
 
@@ -164,6 +169,7 @@ def run_cells(cells, run_cell, seed, rank=None, world=None, group=None):
     return [merged[i] for i in range(len(cells))]
 
 
+@torch.no_grad()
 def share_members(local, n_members, rank=None, world=None, group=None):
     """Ensemble weights after sharded training (config 5): member m was trained on rank m % world and `local[m]` holds
     its flat fp32 blob there.  Returns the list of all n_members blobs on every rank (one broadcast per member from
@@ -176,8 +182,9 @@ def share_members(local, n_members, rank=None, world=None, group=None):
     for m in range(n_members):
         owner = m % world
         buf = local[m].contiguous() if owner == rank else torch.empty_like(ref)
-        dist.broadcast(buf, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
-        out.append(buf)
+        wire = buf.cpu() if (buf.is_cuda and dist.get_backend(group) == 'gloo') else buf
+        dist.broadcast(wire, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
+        out.append(buf if wire is buf else wire.to(buf.device))
     return out
 
 
