@@ -10,6 +10,7 @@
 // [M][5*512] im2col matrix is never materialised.  LayerNorm (affine) + exact GELU are fused
 // in one HBM-bound pass that also rounds to bf16 for the next GEMM.
 #include <math.h>
+#include <stdlib.h>
 
 #include <vector>
 
@@ -19,6 +20,29 @@
 #include "prof.h"
 
 int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, const int* shifts, hipStream_t stream);
+
+static int launch_ln_gelu(const float* x, const float* w, const float* b, bf16_t* out, int M, int H, hipStream_t st);
+
+// GEMM -> LayerNorm -> GELU -> bf16.  Big batches take the full-row persistent kernel that normalises in its epilogue
+// (gemm_p.hip, EPI_LN_GELU: the fp32 pre-LayerNorm activations never reach HBM); small ones, other widths, or
+// SGPO_BYTENET_FUSED_LN=0 (A/B measurements, tests) take the fp32-output GEMM and the separate pass.
+// The fused kernel writes `out_fused` (it must not alias the operand: other tiles still read it); the two-pass form
+// writes fp32 to `c32` and then bf16 to `out_pass` (which may be the operand's buffer).  *used = where the result is.
+static int gemm_ln_gelu(GemmParams g, const float* ln_w, const float* ln_b, float* c32, bf16_t* out_fused, bf16_t* out_pass,
+                        const bf16_t** used, int n_seg, int seg_k, const int* shifts, hipStream_t st) {
+  const char* e = getenv("SGPO_BYTENET_FUSED_LN");
+  if (!(e && e[0] == '0')) {
+    GemmParams f = g;
+    f.C = out_fused; f.ln_w = ln_w; f.ln_b = ln_b; f.ln_eps = 1e-5f;
+    const int rc = launch_gemm_ln_gelu(f, n_seg, seg_k, shifts, st);
+    if (rc != SGPO_ERR_UNSUPPORTED) { *used = out_fused; return rc; }
+  }
+  g.C = c32;
+  int rc = launch_gemm_bf16_seg(g, EPI_BIAS_F32, n_seg, seg_k, shifts, st);
+  if (rc) return rc;
+  *used = out_pass;
+  return launch_ln_gelu(c32, ln_w, ln_b, out_pass, g.M, g.N, st);
+}
 
 struct BnLayer {
   const float *ln1_w, *ln1_b, *b1, *ln2_w, *ln2_b, *bc, *ln3_w, *ln3_b, *b2;
@@ -249,21 +273,19 @@ extern "C" int sgpo_bytenet_forward(sgpo_bytenet* m, const int64_t* tokens, cons
     if (rc) return rc;
     GemmParams g = {};
     g.A = w.a; g.W = l.w1; g.C = w.c; g.bias = l.b1; g.M = M; g.N = H; g.K = D; g.lda = D; g.ldw = D; g.ldc = H; g.L = L; g.B = B;
-    rc = launch_gemm_bf16(g, EPI_BIAS_F32, st);
-    if (rc) return rc;
-    rc = launch_ln_gelu(w.c, l.ln2_w, l.ln2_b, w.d, M, H, st);
+    const bf16_t *h1 = nullptr, *h2 = nullptr;
+    rc = gemm_ln_gelu(g, l.ln2_w, l.ln2_b, w.c, w.d, w.d, &h1, 1, D, nullptr, st);
     if (rc) return rc;
     int shifts[8];
     for (int tap = 0; tap < K; ++tap) shifts[tap] = (tap - K / 2) * l.dilation;
     g = GemmParams{};
-    g.A = w.d; g.W = l.wc; g.C = w.c; g.bias = l.bc; g.M = M; g.N = H; g.K = K * H; g.lda = H; g.ldw = K * H; g.ldc = H;
+    g.A = h1; g.W = l.wc; g.C = w.c; g.bias = l.bc; g.M = M; g.N = H; g.K = K * H; g.lda = H; g.ldw = K * H; g.ldc = H;
     g.L = L; g.B = B;
-    rc = launch_gemm_bf16_seg(g, EPI_BIAS_F32, K, H, shifts, st);
-    if (rc) return rc;
-    rc = launch_ln_gelu(w.c, l.ln3_w, l.ln3_b, w.d, M, H, st);
+    // fused: the bf16 result goes to the (then unused) fp32 scratch; two-pass: back into the operand's buffer
+    rc = gemm_ln_gelu(g, l.ln3_w, l.ln3_b, w.c, reinterpret_cast<bf16_t*>(w.c), w.d, &h2, K, H, shifts, st);
     if (rc) return rc;
     g = GemmParams{};
-    g.A = w.d; g.W = l.w2; g.C = w.x; g.xin = w.x; g.bias = l.b2; g.M = M; g.N = D; g.K = H; g.lda = H; g.ldw = H; g.ldc = D;
+    g.A = h2; g.W = l.w2; g.C = w.x; g.xin = w.x; g.bias = l.b2; g.M = M; g.N = D; g.K = H; g.lda = H; g.ldw = H; g.ldc = D;
     g.L = L; g.B = B;
     rc = launch_gemm_bf16(g, EPI_RES, st);
     if (rc) return rc;

@@ -19,6 +19,7 @@ enum GemmEpi {
   EPI_BIAS_GELU_ERF = 5,  // C bf16 = gelu_erf(acc + bias)
   EPI_RES = 6,         // Xout f32 = Xin + acc + bias
   EPI_ACC_F32 = 7,     // C f32 += acc (+bias)  (multi-tap convolution accumulation)
+  EPI_LN_GELU = 8,     // C bf16 = gelu_erf(LayerNorm(acc + bias) * ln_w + ln_b); N = 512 = one tile row (gemm_p.hip only)
 };
 
 struct GemmParams {
@@ -40,6 +41,10 @@ struct GemmParams {
   // A row remap for dilated convolution taps: source row = row + row_shift when it stays
   // inside the same sequence, else the operand row is treated as zero.
   int row_shift;
+  // EPI_LN_GELU: affine LayerNorm over the N outputs of a row, then exact GELU
+  const float* ln_w;
+  const float* ln_b;
+  float ln_eps;
 };
 
 // Epilogue arithmetic shared by both GEMM kernels (gemm.hip, gemm_p.hip).  Every fused multiply-add is
@@ -79,6 +84,20 @@ __device__ __forceinline__ f32x2_t epi_gelu_tanh2(f32x2_t x) {
 __device__ __forceinline__ float epi_gelu_erf(float x) {
   return rn_mul(rn_mul(0.5f, x), 1.0f + erff(rn_mul(x, 0.7071067811865476f)));
 }
+// exact-GELU for an output that is rounded to bf16 right away: erf by Abramowitz-Stegun 7.1.26 (|error| <= 1.5e-7, five
+// fmas + v_rcp_f32 + v_exp_f32, a handful of registers -- erff's two-branch expansion does not fit beside 128
+// accumulators).  The negative side is formed as x * 0.5 * (1 - erf|.|) = x * 0.5 * poly * exp(-z^2) without the
+// cancellation of 1 + erf, so the tail keeps its relative accuracy.
+__device__ __forceinline__ float epi_gelu_erf_fast(float x) {
+  const float z = fabsf(x) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.0f));
+  float pl = fmaf(1.061405429f, t, -1.453152027f);
+  pl = fmaf(pl, t, 1.421413741f);
+  pl = fmaf(pl, t, -0.284496736f);
+  pl = fmaf(pl, t, 0.254829592f);
+  const float pe = pl * t * __builtin_amdgcn_exp2f(z * z * -1.4426950408889634f);   // 1 - erf(z)
+  return x * (x < 0.f ? 0.5f * pe : fmaf(-0.5f, pe, 1.0f));
+}
 __device__ __forceinline__ void epi_rope(float a, float b, float cs, float sn, float& o0, float& o1) {
   o0 = fmaf(a, cs, -rn_mul(b, sn));   // x1 cos - x2 sin
   o1 = fmaf(a, sn, rn_mul(b, cs));    // x1 sin + x2 cos
@@ -101,5 +120,8 @@ int launch_gemm_bf16(const GemmParams& p, int epi, hipStream_t stream);
 int launch_gemm_bf16_seg(const GemmParams& p, int epi, int n_seg, int seg_k, const int* shifts, hipStream_t stream);
 // persistent 256x128 kernel (gemm_p.hip); returns SGPO_ERR_UNSUPPORTED when the shape does not fit it
 int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, const bf16_t* zero16, hipStream_t stream);
+// GEMM + bias + LayerNorm + GELU in one kernel (full-row tiles); SGPO_ERR_UNSUPPORTED when the shape does not fit
+// (N != 512, few rows): the caller then runs the EPI_BIAS_F32 GEMM and the separate LayerNorm + GELU pass
+int launch_gemm_ln_gelu(const GemmParams& p, int n_seg, int seg_k, const int* shifts, hipStream_t stream);
 int gemm_get_zero16(const bf16_t** out);
 int gemm_cu_count();

@@ -41,16 +41,17 @@ typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
 
 struct CfgBig { static constexpr int WM = 2, WN = 4, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
 struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NST = 3, PH = 2; };
-#ifdef SGPO_GEMM_ABLATE
-// Diagnostic build only: a 128 x 512 tile (whole rows of the hidden width 512 in one workgroup), K loop only -- the two
-// slots fill the LDS, so there is no bias table and no epilogue.  It prices the operand traffic of the full-row tile
-// that a fused residual + LayerNorm epilogue would need (SGPO_GEMM_TILE=r).
+// Full-row tile for N = 512: 128 rows x 512 columns, BK 64, 2-slot ring (the whole 160 KiB), waves 1(M) x 8(N), wave tile
+// 128x64 as in CfgBig.  One workgroup owns whole output rows, so an epilogue can normalise over the row (EPI_LN_GELU): the
+// eight waves exchange per-row partial statistics through the A region of the free ring slot between two extra barriers.
+// Operand traffic per flop is 1.25x that of 256x256; the K loop alone measured 647 vs 608 us on the out-proj/fc2 shapes
+// (DESIGN.md section 6).  No LDS is left for the bias table: bias and the LayerNorm affine come from global memory (L2).
 struct CfgRow { static constexpr int WM = 1, WN = 8, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
 template <typename C> struct is_row_cfg : std::is_same<C, CfgRow> {};
-#else
-template <typename C> struct is_row_cfg : std::false_type {};
-#endif
 
+#ifndef LNG_V
+#define LNG_V 2
+#endif
 enum { PF_EXACT = 1 };
 #define LDS_MAX_BYTES 163840
 
@@ -136,6 +137,28 @@ __device__ __forceinline__ void lds_read_rows(u32x4_t (&o)[4], uint32_t a0, uint
       : "memory");
 }
 __device__ __forceinline__ uint32_t lds_addr(const void* p) { return (uint32_t)(size_t)(lptr_t)(p); }
+typedef float f32x2_vt __attribute__((ext_vector_type(2)));
+// 8 x 8 B at addr + 1024 i (one per wave of the workgroup), read and waited for inside the statement
+__device__ __forceinline__ void lds_read8x8(f32x2_vt (&o)[8], uint32_t addr) {
+  asm volatile(
+      "ds_read_b64 %0, %8\n\t"
+      "ds_read_b64 %1, %8 offset:1024\n\t"
+      "ds_read_b64 %2, %8 offset:2048\n\t"
+      "ds_read_b64 %3, %8 offset:3072\n\t"
+      "ds_read_b64 %4, %8 offset:4096\n\t"
+      "ds_read_b64 %5, %8 offset:5120\n\t"
+      "ds_read_b64 %6, %8 offset:6144\n\t"
+      "ds_read_b64 %7, %8 offset:7168\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(addr)
+      : "memory");
+}
+// x of this lane + x of lane ^ 32 (the same bits in both lanes): one v_permlane32_swap, no LDS
+__device__ __forceinline__ float half_pair_sum(float x) {
+  const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
 
 template <int EPI, bool CONV, typename CFG, bool ROPE_LDS>
 __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16, int ntm, int ntn,
@@ -158,11 +181,14 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr bool PRE = RES && MT * NT * 4 <= 16;
   constexpr bool STAGED32 = (RES && !PRE) || F32ST;
   constexpr bool HAS_X = RES || EPI == EPI_ACC_F32;   // the epilogue adds what the output location holds / xin
+  constexpr bool ROW = is_row_cfg<CFG>::value;        // no aux tables in LDS; bf16 staging halves both in the B pieces
+  constexpr bool LNG = (EPI == EPI_LN_GELU);
+  static_assert(!LNG || (ROW && MT == 4), "row statistics need the whole row in one workgroup");
   constexpr int E_ST = STAGED32 ? MT * 8 : (PRE || F32OUT) ? MT * NT * 4 : MT * 4;
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
   static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
-  static_assert(!STAGED32 || (A_PW >= 4 && B_PW >= 4) || is_row_cfg<CFG>::value, "fp32 output staging: 32 x 64 block = two 4-KiB halves");
+  static_assert(!STAGED32 || (A_PW >= 4 && B_PW >= 4) || ROW, "fp32 output staging: 32 x 64 block = two 4-KiB halves");
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -203,7 +229,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   };
 
   // ---- aux tables -> LDS (once per launch; the only ordinary loads outside RES / fp32-out epilogues)
-  if constexpr ((!F32OUT || F32ST) && !is_row_cfg<CFG>::value) {
+  if constexpr ((!F32OUT || F32ST) && !ROW) {
     if constexpr (EPI == EPI_QKV_ROPE) {
       if constexpr (ROPE_LDS) {
         const int n = p.L * (p.head_dim / 2);
@@ -226,19 +252,23 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   tile_origin(0, st_m0, st_n0);
   // per-lane byte offsets of the DMA pieces inside a full tile (row * ld + swizzled chunk): constant for
   // the whole launch, so staging a full tile costs one scalar base per operand + OPS DMA instructions
-  uint32_t a_off[A_PW], w_off[B_PW];
+  // (pieces j and j + 2 of an operand are 16 rows apart and share the swizzle term, so two offsets per operand and a
+  //  scalar row stride describe them all)
+  static_assert(CH == 8 && A_PW % 2 == 0 && B_PW % 2 == 0, "piece offsets: 128-B rows, pairs of pieces");
+  uint32_t a_off[2], w_off[2];
 #pragma unroll
-  for (int j = 0; j < A_PW; ++j) {
+  for (int j = 0; j < 2; ++j) {
     const int row = (wave * A_PW + j) * RPI + lane / CH;
-    const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+    const int c = (lane % CH) ^ ((row >> 1) & 7);
     a_off[j] = ((uint32_t)row * (uint32_t)p.lda + c * 8) * 2;
   }
 #pragma unroll
-  for (int j = 0; j < B_PW; ++j) {
+  for (int j = 0; j < 2; ++j) {
     const int row = (wave * B_PW + j) * RPI + lane / CH;
-    const int c = (lane % CH) ^ (CH == 8 ? (row >> 1) & 7 : (row >> 2) & 3);
+    const int c = (lane % CH) ^ ((row >> 1) & 7);
     w_off[j] = ((uint32_t)row * (uint32_t)p.ldw + c * 8) * 2;
   }
+  const size_t a_pair = (size_t)(2 * RPI) * p.lda * 2, w_pair = (size_t)(2 * RPI) * p.ldw * 2;   // bytes between pieces j, j + 2
   auto stage = [&](int slot) {
     const int kglob = st_kt * BK;
     char* abase = smem + slot * STAGE;
@@ -248,10 +278,10 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       const char* wg = reinterpret_cast<const char*>(p.W + (size_t)st_n0 * p.ldw + kglob);
 #pragma unroll
       for (int j = 0; j < A_PW; ++j)
-        __builtin_amdgcn_global_load_lds((gptr_t)(ag + a_off[j]), (lptr_t)(abase + (wave * A_PW + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(ag + (j >> 1) * a_pair + a_off[j & 1]), (lptr_t)(abase + (wave * A_PW + j) * 1024), 16, 0, 0);
 #pragma unroll
       for (int j = 0; j < B_PW; ++j)
-        __builtin_amdgcn_global_load_lds((gptr_t)(wg + w_off[j]), (lptr_t)(bbase + (wave * B_PW + j) * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gptr_t)(wg + (j >> 1) * w_pair + w_off[j & 1]), (lptr_t)(bbase + (wave * B_PW + j) * 1024), 16, 0, 0);
     } else {
       int kin = kglob, sh = 0;
       if constexpr (CONV) {
@@ -308,17 +338,24 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // destinations), so no other wave touches it and no barrier is needed.  Image: row r at
   // (r & 15) * 128 in half r >> 4; 16-B chunk ch at ch ^ (r & 7); the 8-B halves of a chunk are
   // swapped when r & 8 (conflict-free ds_write_b64 for the 16-lane groups).
-  auto store_block = [&](const u32x2_t (&pk)[NT][4], int m_blk, int nb0, int fslot, auto full_tag) {
-    constexpr bool FULL = decltype(full_tag)::value;
+  auto blk_h0 = [&](int fslot) {
     char* fs = smem + fslot * STAGE;
-    const uint32_t h0 = lds_addr(fs + (wave * A_PW) * 1024);
-    const uint32_t h1 = (A_PW >= 4) ? h0 + 2048 : lds_addr(fs + A_BYTES + (wave * B_PW) * 1024);
+    return ROW ? lds_addr(fs + A_BYTES + (wave * B_PW) * 1024) : lds_addr(fs + (wave * A_PW) * 1024);
+  };
+  auto blk_h1 = [&](int fslot, uint32_t h0) {
+    return (ROW || A_PW >= 4) ? h0 + 2048 : lds_addr(smem + fslot * STAGE + A_BYTES + (wave * B_PW) * 1024);
+  };
+  // one column quad (nt, g) of this lane's row into the block image
+  auto block_put = [&](uint32_t h0, uint32_t h1, int nt, int g, u32x2_t v, int lr, int lh) {
     const uint32_t wbase = ((lr >> 4) ? h1 : h0) + (lr & 15) * 128 + ((lh ^ ((lr >> 3) & 1)) << 3);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) lds_write8(wbase + (((nt * 4 + g) ^ (lr & 7)) << 4), pk[nt][g]);
-    const int r8 = lane >> 3, c8 = lane & 7;
+    lds_write8(wbase + (((nt * 4 + g) ^ (lr & 7)) << 4), v);
+  };
+  // the block image back as whole lines, to global memory
+  auto block_flush = [&](uint32_t h0, uint32_t h1, int m_blk, int nb0, auto full_tag) {
+    constexpr bool FULL = decltype(full_tag)::value;
+    int le = lane;
+    if constexpr (LNG) asm volatile("" : "+v"(le));   // addresses formed here, not kept in registers across the K loop
+    const int r8 = le >> 3, c8 = le & 7;
     const uint32_t roff = r8 * 128 + ((c8 ^ r8) << 4);
     u32x4_t o[4];
     lds_read_rows(o, h0 + roff, h1 + roff);
@@ -332,6 +369,14 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       if (FULL || m_blk + i * 8 + r8 < p.M)
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc));   // streamed once: keep L2 for the operand panels
     }
+  };
+  auto store_block = [&](const u32x2_t (&pk)[NT][4], int m_blk, int nb0, int fslot, auto full_tag) {
+    const uint32_t h0 = blk_h0(fslot), h1 = blk_h1(fslot, h0);
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) block_put(h0, h1, nt, g, pk[nt][g], lr, lh);
+    block_flush(h0, h1, m_blk, nb0, full_tag);
   };
 
   // fp32 residual epilogue of the 256x256 tile, one mt block (32 rows x 64 columns, 8 KiB) at a time:
@@ -443,6 +488,113 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
                 C[(size_t)m * p.ldc + n + q] = o;
               }
           }
+      }
+    } else if constexpr (LNG) {
+      // bias, then LayerNorm over the 512 outputs of each row, affine, exact GELU, bf16.  A lane holds 32 of a row's
+      // values per mt (its partner lane ^ 32 the other 32 of the wave's 64 columns), the other seven waves the rest.
+      // Each wave reduces its 64 columns to (mean_w, M2_w = sum of squared deviations from mean_w); the eight partials
+      // are combined exactly (Chan et al.): mean = avg(mean_w), M2 = sum M2_w + 64 sum (mean_w - mean)^2 -- as accurate
+      // as the two-pass form of ln_gelu_kernel, one exchange.  Partials live in the A region of the free slot
+      // ([wave][mt][row] float2, 8 KiB): written, barrier, read by every wave, barrier (the next prefetch overwrites
+      // it).  Both wave groups run their epilogue in the same barrier interval, so the two extra barriers pair up.
+      const uint32_t st_base = lds_addr(smem + fslot * STAGE);
+#if LNG_V >= 3
+      int te = tid;
+      asm volatile("" : "+v"(te));   // lane-derived values of the epilogue come from the thread id here, not from registers carried through the K loop
+      const int lr = te & 31, lh = (te >> 5) & 1;
+#endif
+      // (the accumulators are only read: acc + bias is formed again in each of the three passes, from L1/L2-resident
+      //  bias quads -- updating them in place made the register allocator keep a second copy and spill)
+      float mean[MT], rstd[MT];
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) mean[mt] = 0.f;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+          asm volatile("" : "+v"(n));   // opaque: identical loads of the three passes are not merged (and kept live)
+          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            mean[mt] += ((acc[nt][mt][4 * g + 0] + b4.x) + (acc[nt][mt][4 * g + 1] + b4.y)) +
+                        ((acc[nt][mt][4 * g + 2] + b4.z) + (acc[nt][mt][4 * g + 3] + b4.w));
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) { mean[mt] = half_pair_sum(mean[mt]) * (1.0f / 64.0f); rstd[mt] = 0.f; }
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+          asm volatile("" : "+v"(n));
+          const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+          const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              const float d = (acc[nt][mt][4 * g + q] + bv[q]) - mean[mt];
+              rstd[mt] = fmaf(d, d, rstd[mt]);
+            }
+        }
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const float sq = half_pair_sum(rstd[mt]);
+        if (lh == 0) {
+          u32x2_t w2;
+          w2.x = __float_as_uint(mean[mt]); w2.y = __float_as_uint(sq);
+          lds_write8(st_base + (((wave * MT + mt) * 32 + lr) << 3), w2);
+        }
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x2_vt pw[8];
+        lds_read8x8(pw, st_base + ((mt * 32 + lr) << 3));
+        float ms = 0.f, m2 = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { ms += pw[w].x; m2 += pw[w].y; }
+        const float mu = ms * 0.125f;
+        float dv = 0.f;
+#pragma unroll
+        for (int w = 0; w < 8; ++w) { const float d = pw[w].x - mu; dv = fmaf(d, d, dv); }
+        m2 = fmaf(64.0f, dv, m2);
+        mean[mt] = mu;
+        rstd[mt] = rsqrtf(m2 * (1.0f / (float)BN) + p.ln_eps);
+      }
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m_blk = m0 + mt * 32;
+        const uint32_t h0 = blk_h0(fslot), h1 = blk_h1(fslot, h0);
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+            asm volatile("" : "+v"(n));
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+            const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(p.ln_w + n);
+            const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(p.ln_b + n);
+            const float bv[4] = {b4.x, b4.y, b4.z, b4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
+            float v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              v[q] = epi_gelu_erf_fast(fmaf(rn_mul((acc[nt][mt][4 * g + q] + bv[q]) - mean[mt], rstd[mt]), wv[q], cv[q]));
+#if LNG_V == 1
+              __builtin_amdgcn_sched_barrier(0);
+#endif
+            }
+            block_put(h0, h1, nt, g, pack4(v[0], v[1], v[2], v[3]), lr, lh);
+#if LNG_V != 2 && LNG_V != 3
+            __builtin_amdgcn_sched_barrier(0);   // one quad at a time beside 128 accumulators
+#endif
+          }
+        block_flush(h0, h1, m_blk, nb0, full_tag);
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else if constexpr (STAGED32) {
       char* fs = smem + fslot * STAGE;
@@ -638,10 +790,11 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 #pragma unroll
       for (int k2 = 0; k2 < KP; ++k2) {
         const int kk = ph * KP + k2;
+        const int cxk = cx[kk];
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[k2][t] = *reinterpret_cast<const bf16x8*>(base + b_lane + cx[kk] + t * 32 * ROWB);
+        for (int t = 0; t < NT; ++t) wf[k2][t] = *reinterpret_cast<const bf16x8*>(base + b_lane + cxk + t * 32 * ROWB);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[k2][t] = *reinterpret_cast<const bf16x8*>(base + a_lane + cx[kk] + t * 32 * ROWB);
+        for (int t = 0; t < MT; ++t) xf[k2][t] = *reinterpret_cast<const bf16x8*>(base + a_lane + cxk + t * 32 * ROWB);
       }
       if (ph == PH - 1 && s + 1 < total) {
         int ahead = total - 2 - s;
@@ -698,6 +851,19 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
    for (int kt = 0; kt < nk - 1; ++kt) step(kt, std::false_type{});
    step(nk - 1, std::true_type{});
   }
+  if constexpr (LNG) {
+    // the epilogue holds two barriers of its own: group 0 runs the last one where every other one runs, right after the
+    // tile's last barrier pair and BEFORE its balancing barrier, so that its barriers pair with group 1's epilogue
+    // (which ran at the end of group 1's last M phase); same free slot as group 1 used (slot(e) = slot + D)
+    if (grp == 0) {
+      int pm0, pn0, fslot = slot + D;
+      if (fslot >= NST) fslot -= NST;
+      tile_origin(n_my - 1, pm0, pn0);
+      epilogue(pm0, pn0, fslot, std::false_type{});
+      __builtin_amdgcn_s_barrier();
+    }
+    return;
+  }
   if (grp == 0 && !ABL(8)) __builtin_amdgcn_s_barrier();
   if (!ABL(4) && !(EARLY1 && grp == 1)) {
     int pm0, pn0;
@@ -730,7 +896,7 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   } else if (!F32OUT || CFG::MT * CFG::NT * 4 > 16) {
     aux = (size_t)q.N * sizeof(float);
   }
-  if (is_row_cfg<CFG>::value) aux = 0;
+  if (is_row_cfg<CFG>::value) aux = 0;   // the ring fills the LDS
   if (RING + aux > LDS_MAX_BYTES) return SGPO_ERR_UNSUPPORTED;
   const int ntm = (q.M + BM - 1) / BM, ntn = (q.N + BN - 1) / BN;
   const int tiles = ntm * ntn;
@@ -785,12 +951,14 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   GemmParams q = p;
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
   const bool big = tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096 && p.ldc % 4 == 0;
-  ProfScope prof_scope(PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
+  if (epi == EPI_LN_GELU && (p.N != 512 || !p.ln_w || !p.ln_b || ((p.M + 127) / 128) < n_cu / 2)) return SGPO_ERR_UNSUPPORTED;
+  ProfScope prof_scope(epi == EPI_LN_GELU ? PK_GEMM_LN_GELU : PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
 #ifdef SGPO_GEMM_ABLATE
   if (tile_mode == 2 && epi == EPI_GATE_RES && p.N == 512)   // K loop of the full-row tile, no epilogue (bit 4 forced)
     return launch_cfg<EPI_GATE_RES, CfgRow>(q, sg, zero16, n_cu, dbg | 4, stream);
 #endif
+  if (epi == EPI_LN_GELU) return launch_cfg<EPI_LN_GELU, CfgRow>(q, sg, zero16, n_cu, dbg, stream);
 #define LAUNCH_BOTH(E)                                                              \
   case E:                                                                           \
     if (big) rc = launch_cfg<E, CfgBig>(q, sg, zero16, n_cu, dbg, stream);          \
@@ -818,4 +986,17 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #undef LAUNCH_BOTH
 #undef LAUNCH_RES
   return rc;
+}
+
+int launch_gemm_ln_gelu(const GemmParams& p, int n_seg, int seg_k, const int* shifts, hipStream_t stream) {
+  if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || n_seg < 1 || n_seg > 8 || seg_k % 64 != 0 || n_seg * seg_k != p.K ||
+      p.lda % 8 != 0 || p.ldw % 8 != 0 || p.ldc % 8 != 0 || p.L <= 0)
+    return SGPO_ERR_UNSUPPORTED;
+  GemmSeg sg;
+  sg.n_seg = n_seg; sg.seg_k = seg_k;
+  for (int i = 0; i < 8; ++i) sg.shift[i] = (shifts && i < n_seg) ? shifts[i] : 0;
+  const bf16_t* z = nullptr;
+  const int rc = gemm_get_zero16(&z);
+  if (rc) return rc;
+  return launch_gemm_persistent(p, EPI_LN_GELU, sg, z, stream);
 }

@@ -135,6 +135,38 @@ def test_bytenet_forward_large_batch_matches_small_batch(rt):
         assert torch.equal(hsmall, hbig[sl]) and torch.equal(small, big[sl])
 
 
+def test_bytenet_fused_layernorm_gemm_vs_two_pass_and_oracle(rt, monkeypatch):
+    """M = 44 x 389 = 17116 rows (ragged last 128-row tile): the PFF1 and dilated-conv GEMMs take the full-row persistent
+    kernel whose epilogue does bias + LayerNorm + GELU (gemm_p.hip EPI_LN_GELU).  Checked against the CPU restatement to
+    the tolerance of the two-pass form, and against the two-pass form itself (SGPO_BYTENET_FUSED_LN=0): the two differ
+    only in the fp32 summation order of the row statistics, the erf approximation (1.5e-7) and hence in an occasional
+    bf16 rounding of an activation."""
+    from oracle import bytenet as obn
+    from sgpo_amd import weights as W
+    sd = W.bytenet_synthetic_state(seed=5, n_layers=3)
+    net = rt.BytenetDenoiser(sd)
+    g = torch.Generator().manual_seed(6)
+    B, L = 44, 389
+    x = torch.randint(0, S, (B, L), generator=g)
+    tt = torch.randint(1, 500, (B,), generator=g)
+    got, hid = net.forward(x.cuda(), tt.cuda(), return_hidden=True)
+    monkeypatch.setenv('SGPO_BYTENET_FUSED_LN', '0')
+    got2, hid2 = net.forward(x.cuda(), tt.cuda(), return_hidden=True)
+    monkeypatch.delenv('SGPO_BYTENET_FUSED_LN')
+    again, _ = net.forward(x.cuda(), tt.cuda(), return_hidden=True)
+    assert torch.equal(again, got)                                     # deterministic
+    assert not torch.equal(hid, hid2)                                  # the fused kernel really ran
+    d = (hid - hid2).abs().max() / hid2.abs().max()
+    print(f'fused vs two-pass: hidden {d:.3e} of the range, logits {(got - got2).abs().max() / got2.abs().max():.3e}')
+    assert d < 5e-3
+    ref, href = obn.bytenet_forward(sd, x[:6], tt[:6], return_hidden=True)
+    eh = (hid[:6].cpu() - href).abs().max() / href.abs().max()
+    el = (got[:6].cpu() - ref).abs().max() / ref.abs().max()
+    eh2 = (hid2[:6].cpu() - href).abs().max() / href.abs().max()
+    print(f'vs oracle: fused hidden {eh:.3e} logits {el:.3e}; two-pass hidden {eh2:.3e}')
+    assert eh < 2e-2 and el < 3e-2
+
+
 def _mh_setup(rt, g):
     from sgpo_amd import weights as W
     res1 = [int(r) for r in g['residues']]
