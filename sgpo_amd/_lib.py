@@ -11,7 +11,7 @@ LIB_PATH = os.environ.get('SGPO_HIP_LIB') or os.path.join(_HERE, 'libsgpo_hip.so
 
 NOISE_PHILOX, NOISE_EXPONENTIAL, NOISE_UNIFORM, NOISE_NONE = 0, 1, 2, 3
 STEP_SOFT, STEP_SOFT_CG, STEP_HARD = 0, 1, 2
-PROF_KINDS = 19
+PROF_KINDS = 20
 
 
 class SgpoError(RuntimeError):

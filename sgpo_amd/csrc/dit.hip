@@ -1,6 +1,7 @@
 // Host side of the MDLM denoiser: weight handle + the per-forward launch sequence.
 // Reference: DIT.forward (dit.py:375-418), DDiTBlock.forward (dit.py:244-288),
 // DDitFinalLayer.forward (dit.py:317-321).
+#include <stdlib.h>
 #include <stdarg.h>
 #include <stdio.h>
 #include <vector>
@@ -220,14 +221,33 @@ extern "C" int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float*
   if (rc) return rc;
 
   const float* xcur;
+  bool xn_ready = false;   // w.xn already holds the final layer's LayerNorm-modulate of xcur
   if (!x_emb) {
     rc = launch_embed(tokens, m->embed, w.x, M, H, c.vocab, st);
     if (rc) return rc;
+    // out-projection / fc2 GEMM + gate + residual + the LayerNorm-modulate that follows in one kernel where the shape
+    // allows (gemm_p.hip EPI_GATE_RES_LN: the separate HBM pass over the residual stream disappears); otherwise, or
+    // with SGPO_DIT_FUSED_LN=0 (A/B measurements, tests), the GEMM and the pass.  Same bits either way (ln_stats.h).
+    const char* fe = getenv("SGPO_DIT_FUSED_LN");
+    const bool try_fused = !(fe && fe[0] == '0');
+    auto gate_res_then_ln = [&](GemmParams g, const float* ln_w, const float* shift, const float* scale) -> int {
+      if (try_fused) {
+        GemmParams f = g;
+        f.ln_w = ln_w; f.ln_shift = shift; f.ln_scale = scale; f.ln_out = w.xn; f.ln_eps = 1e-5f;
+        const int r = launch_gemm_gate_res_ln(f, st);
+        if (r != SGPO_ERR_UNSUPPORTED) return r;
+      }
+      const int r = launch_gemm_bf16(g, EPI_GATE_RES, st);
+      if (r) return r;
+      return launch_ln_mod(w.x, ln_w, shift, scale, mod_stride, w.xn, M, L, B, H, st);
+    };
     for (int i = 0; i < c.n_blocks; ++i) {
       const DitBlockW& b = m->blocks[i];
       const float* mod = w.mod + (size_t)i * 6 * H;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-      rc = launch_ln_mod(w.x, b.norm1, mod, mod + H, mod_stride, w.xn, M, L, B, H, st);
-      if (rc) return rc;
+      if (i == 0) {   // (the later blocks' first LayerNorm rides on the fc2 GEMM of the block before)
+        rc = launch_ln_mod(w.x, b.norm1, mod, mod + H, mod_stride, w.xn, M, L, B, H, st);
+        if (rc) return rc;
+      }
       GemmParams g = {};
       g.A = w.xn; g.W = b.qkv; g.C = w.qkv; g.M = M; g.N = 3 * H; g.K = H; g.lda = H; g.ldw = H; g.ldc = 3 * H;
       g.L = L; g.B = B; g.rope_cos = m->rope_cos; g.rope_sin = m->rope_sin; g.rope_cols = 2 * H; g.head_dim = 64;
@@ -238,9 +258,7 @@ extern "C" int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float*
       g = GemmParams{};
       g.A = w.att; g.W = b.attn_out; g.C = w.x; g.xin = w.x; g.M = M; g.N = H; g.K = H; g.lda = H; g.ldw = H; g.ldc = H;
       g.L = L; g.B = B; g.gate = mod + 2 * H; g.gate_stride = mod_stride;
-      rc = launch_gemm_bf16(g, EPI_GATE_RES, st);
-      if (rc) return rc;
-      rc = launch_ln_mod(w.x, b.norm2, mod + 3 * H, mod + 4 * H, mod_stride, w.xn, M, L, B, H, st);
+      rc = gate_res_then_ln(g, b.norm2, mod + 3 * H, mod + 4 * H);
       if (rc) return rc;
       g = GemmParams{};
       g.A = w.xn; g.W = b.fc1; g.C = w.mid; g.bias = b.fc1_b; g.M = M; g.N = F; g.K = H; g.lda = H; g.ldw = H; g.ldc = F;
@@ -250,9 +268,12 @@ extern "C" int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float*
       g = GemmParams{};
       g.A = w.mid; g.W = b.fc2; g.C = w.x; g.xin = w.x; g.bias = b.fc2_b; g.M = M; g.N = H; g.K = F; g.lda = F; g.ldw = F;
       g.ldc = H; g.L = L; g.B = B; g.gate = mod + 5 * H; g.gate_stride = mod_stride;
-      rc = launch_gemm_bf16(g, EPI_GATE_RES, st);
+      const bool last = i + 1 == c.n_blocks;
+      const float* nmod = last ? w.mod + (size_t)c.n_blocks * 6 * H : mod + 6 * H;   // next block's (shift, scale) or the final layer's
+      rc = gate_res_then_ln(g, last ? m->out_norm : m->blocks[i + 1].norm1, nmod, nmod + H);
       if (rc) return rc;
     }
+    xn_ready = true;
     xcur = w.x;
   } else {
     xcur = x_emb;
@@ -263,8 +284,10 @@ extern "C" int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float*
   }
   // final layer: LN-modulate + Linear(hidden -> vocab)
   const float* fmod = w.mod + (size_t)c.n_blocks * 6 * H;  // shift, scale
-  rc = launch_ln_mod(xcur, m->out_norm, fmod, fmod + H, mod_stride, w.xn, M, L, B, H, st);
-  if (rc) return rc;
+  if (!xn_ready) {
+    rc = launch_ln_mod(xcur, m->out_norm, fmod, fmod + H, mod_stride, w.xn, M, L, B, H, st);
+    if (rc) return rc;
+  }
   GemmParams g = {};
   g.A = w.xn; g.W = m->out_lin; g.C = logits; g.bias = m->out_lin_b; g.M = M; g.N = c.vocab; g.K = H; g.lda = H; g.ldw = H;
   g.ldc = c.vocab; g.L = L; g.B = B;

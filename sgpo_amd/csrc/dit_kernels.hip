@@ -2,6 +2,7 @@
 // embedding gather, LayerNorm+modulate, short-sequence attention.
 // Reference: models/pretraining/model/mdlm/models/dit.py (line refs per kernel).
 #include "common.h"
+#include "ln_stats.h"
 #include "dit.h"
 #include "prof.h"
 
@@ -102,14 +103,32 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
     float4 t = reinterpret_cast<const float4*>(xr)[i * 64 + lane];
     v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
   }
-  float s = 0.f;
+  float mean, rstd;
+  if constexpr (H == 512) {
+    // the summation order of ln_stats.h (= the fused GEMM epilogue): quad i of lane l is quad l % 16 of segment
+    // 4 i + l / 16; the eight segment statistics are fetched from the first lane of their DPP row
+    float ms[8], qs[8];
 #pragma unroll
-  for (int i = 0; i < PER; ++i) s += v[i];
-  const float mean = wave_sum(s) * (1.0f / H);
-  float q = 0.f;
+    for (int i = 0; i < 2; ++i) {
+      float m_s, q_s;
+      lns_segment(v[i * 4 + 0], v[i * 4 + 1], v[i * 4 + 2], v[i * 4 + 3], m_s, q_s);
 #pragma unroll
-  for (int i = 0; i < PER; ++i) { float d = v[i] - mean; q += d * d; }
-  const float rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+      for (int r = 0; r < 4; ++r) {
+        ms[i * 4 + r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(m_s), 16 * r));
+        qs[i * 4 + r] = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(q_s), 16 * r));
+      }
+    }
+    lns_combine8(ms, qs, 1e-5f, mean, rstd);
+  } else {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) s += v[i];
+    mean = wave_sum(s) * (1.0f / H);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { float d = v[i] - mean; q += d * d; }
+    rstd = rsqrtf(wave_sum(q) * (1.0f / H) + 1e-5f);
+  }
   int b = row / L;
   if (b > B - 1) b = B - 1;
   const float* sh = shift + (size_t)b * mod_stride;
@@ -120,13 +139,9 @@ __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x
     float4 ww = *reinterpret_cast<const float4*>(w + col);
     float4 s4 = *reinterpret_cast<const float4*>(sh + col);
     float4 c4 = *reinterpret_cast<const float4*>(sc + col);
-    float o0 = (v[i * 4 + 0] - mean) * rstd * ww.x * (1.f + c4.x) + s4.x;
-    float o1 = (v[i * 4 + 1] - mean) * rstd * ww.y * (1.f + c4.y) + s4.y;
-    float o2 = (v[i * 4 + 2] - mean) * rstd * ww.z * (1.f + c4.z) + s4.z;
-    float o3 = (v[i * 4 + 3] - mean) * rstd * ww.w * (1.f + c4.w) + s4.w;
     uint2 pk;
-    pk.x = pack_bf16x2(o0, o1);
-    pk.y = pack_bf16x2(o2, o3);
+    pk.x = pack_bf16x2(lns_modulate(v[i * 4 + 0], mean, rstd, ww.x, c4.x, s4.x), lns_modulate(v[i * 4 + 1], mean, rstd, ww.y, c4.y, s4.y));
+    pk.y = pack_bf16x2(lns_modulate(v[i * 4 + 2], mean, rstd, ww.z, c4.z, s4.z), lns_modulate(v[i * 4 + 3], mean, rstd, ww.w, c4.w, s4.w));
     *reinterpret_cast<uint2*>(out + (size_t)row * H + col) = pk;
   }
 }

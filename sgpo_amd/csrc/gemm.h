@@ -20,6 +20,7 @@ enum GemmEpi {
   EPI_RES = 6,         // Xout f32 = Xin + acc + bias
   EPI_ACC_F32 = 7,     // C f32 += acc (+bias)  (multi-tap convolution accumulation)
   EPI_LN_GELU = 8,     // C bf16 = gelu_erf(LayerNorm(acc + bias) * ln_w + ln_b); N = 512 = one tile row (gemm_p.hip only)
+  EPI_GATE_RES_LN = 9, // EPI_GATE_RES, and ln_out bf16 = adaLN-modulated LayerNorm of the new residual row (N = 512, gemm_p.hip only)
 };
 
 struct GemmParams {
@@ -45,6 +46,11 @@ struct GemmParams {
   const float* ln_w;
   const float* ln_b;
   float ln_eps;
+  // EPI_GATE_RES_LN: LayerNorm weight in ln_w; ln_out[m][n] = ((x_new - mean) rstd ln_w[n]) (1 + ln_scale[b][n]) + ln_shift[b][n],
+  // the modulation rows indexed like the gate (b * gate_stride)
+  const float* ln_shift;
+  const float* ln_scale;
+  bf16_t* ln_out;
 };
 
 // Epilogue arithmetic shared by both GEMM kernels (gemm.hip, gemm_p.hip).  Every fused multiply-add is
@@ -123,5 +129,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 // GEMM + bias + LayerNorm + GELU in one kernel (full-row tiles); SGPO_ERR_UNSUPPORTED when the shape does not fit
 // (N != 512, few rows): the caller then runs the EPI_BIAS_F32 GEMM and the separate LayerNorm + GELU pass
 int launch_gemm_ln_gelu(const GemmParams& p, int n_seg, int seg_k, const int* shifts, hipStream_t stream);
+// out-projection / fc2 GEMM + gate + fp32 residual + the NEXT LayerNorm-modulate in one kernel (same contract)
+int launch_gemm_gate_res_ln(const GemmParams& p, hipStream_t stream);
 int gemm_get_zero16(const bf16_t** out);
 int gemm_cu_count();

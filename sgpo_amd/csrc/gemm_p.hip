@@ -30,6 +30,7 @@
 // (row>>1)&7 for 128-B rows or (row>>2)&3 for 64-B rows on the source address and on ds_read_b128:
 // conflict-free for the four 16-lane groups of ds_read_b128).
 #include "gemm.h"
+#include "ln_stats.h"
 #include "prof.h"
 #include <stdlib.h>
 #include <type_traits>
@@ -49,6 +50,9 @@ struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NS
 struct CfgRow { static constexpr int WM = 1, WN = 8, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
 template <typename C> struct is_row_cfg : std::is_same<C, CfgRow> {};
 
+#ifndef RLN_V
+#define RLN_V 0
+#endif
 #ifndef LNG_V
 #define LNG_V 2
 #endif
@@ -154,6 +158,38 @@ __device__ __forceinline__ void lds_read8x8(f32x2_vt (&o)[8], uint32_t addr) {
       : "v"(addr)
       : "memory");
 }
+// 8 x 8 B at addr + 32 i (the final statistics of rows r, r + 4, ..., r + 28)
+__device__ __forceinline__ void lds_read8x8_s32(f32x2_vt (&o)[8], uint32_t addr) {
+  asm volatile(
+      "ds_read_b64 %0, %8\n\t"
+      "ds_read_b64 %1, %8 offset:32\n\t"
+      "ds_read_b64 %2, %8 offset:64\n\t"
+      "ds_read_b64 %3, %8 offset:96\n\t"
+      "ds_read_b64 %4, %8 offset:128\n\t"
+      "ds_read_b64 %5, %8 offset:160\n\t"
+      "ds_read_b64 %6, %8 offset:192\n\t"
+      "ds_read_b64 %7, %8 offset:224\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(addr)
+      : "memory");
+}
+// 8 x 8 B at addr + 256 i (the segment statistics of one row of a 32-row block, one per wave)
+__device__ __forceinline__ void lds_read8x8_s256(f32x2_vt (&o)[8], uint32_t addr) {
+  asm volatile(
+      "ds_read_b64 %0, %8\n\t"
+      "ds_read_b64 %1, %8 offset:256\n\t"
+      "ds_read_b64 %2, %8 offset:512\n\t"
+      "ds_read_b64 %3, %8 offset:768\n\t"
+      "ds_read_b64 %4, %8 offset:1024\n\t"
+      "ds_read_b64 %5, %8 offset:1280\n\t"
+      "ds_read_b64 %6, %8 offset:1536\n\t"
+      "ds_read_b64 %7, %8 offset:1792\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1]), "=&v"(o[2]), "=&v"(o[3]), "=&v"(o[4]), "=&v"(o[5]), "=&v"(o[6]), "=&v"(o[7])
+      : "v"(addr)
+      : "memory");
+}
 // x of this lane + x of lane ^ 32 (the same bits in both lanes): one v_permlane32_swap, no LDS
 __device__ __forceinline__ float half_pair_sum(float x) {
   const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
@@ -170,7 +206,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192, OPS = A_PW + B_PW, D = NST - 1;
   constexpr int PH = CFG::PH, KP = KK / PH;
-  constexpr bool RES = (EPI == EPI_GATE_RES || EPI == EPI_RES);
+  constexpr bool RLN = (EPI == EPI_GATE_RES_LN);
+  constexpr bool RES = (EPI == EPI_GATE_RES || EPI == EPI_RES || RLN);
   constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
   // fp32 output on the 256x256 tile goes out like the fp32 residual: staged through LDS, whole lines (N % 256 == 0)
   constexpr bool F32ST = F32OUT && MT * NT * 4 > 16;
@@ -183,7 +220,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr bool HAS_X = RES || EPI == EPI_ACC_F32;   // the epilogue adds what the output location holds / xin
   constexpr bool ROW = is_row_cfg<CFG>::value;        // no aux tables in LDS; bf16 staging halves both in the B pieces
   constexpr bool LNG = (EPI == EPI_LN_GELU);
-  static_assert(!LNG || (ROW && MT == 4), "row statistics need the whole row in one workgroup");
+  static_assert(!(LNG || RLN) || (ROW && MT == 4), "row statistics need the whole row in one workgroup");
+  constexpr bool ROWSTAT = LNG || RLN;   // the epilogue exchanges row statistics between the waves (barriers of its own)
   constexpr int E_ST = STAGED32 ? MT * 8 : (PRE || F32OUT) ? MT * NT * 4 : MT * 4;
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
   static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
@@ -489,6 +527,113 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
               }
           }
       }
+    } else if constexpr (RLN) {
+      // x_new = x + gate (acc + bias) as in the staged fp32 residual epilogue (same arithmetic, same bits), one 32-row block
+      // at a time: y goes through the wave's own pieces of the free slot and comes back transposed (a lane holds the quad
+      // c16 of rows i*4 + r4), x is loaded and x_new stored in that layout and KEPT in registers.  Per row and wave one
+      // segment statistic (ln_stats.h) goes to the A region of the free slot, [wave][row of the block], double-buffered by
+      // block parity; after ONE barrier every wave combines the eight segments of the block's 32 rows (lane = row), hands
+      // (mean, rstd) to the lanes that hold the row's quads (ds_bpermute) and stores the modulated bf16 row pieces (16 lanes
+      // = one whole 128-B line).  A last barrier keeps the next prefetch from overwriting statistics still being read.
+      char* fs = smem + fslot * STAGE;
+      const uint32_t st_base = lds_addr(fs);          // 2 x [wave][32 rows] (mean_s, M2_s): 4 KiB
+      const uint32_t h0 = lds_addr(fs + A_BYTES + (wave * B_PW) * 1024), h1 = h0 + 4096;
+      // every lane-derived value of the epilogue is formed from this opaque copy, inside the epilogue: derived from `lane`
+      // directly they are tile-invariant, get hoisted out of the persistent loop and stay live through the K loop
+      int le = lane;
+      asm volatile("" : "+v"(le));
+      const int lr = le & 31, lh = le >> 5;
+      const uint32_t wbase = ((lr >> 4) ? h1 : h0) + (lr & 15) * 256;
+      const int r4 = le >> 4, c16 = le & 15;
+      const uint32_t k0 = r4 * 256 + ((c16 ^ r4) << 4), k1 = r4 * 256 + ((c16 ^ (r4 + 4)) << 4);
+      const bool per_seq = p.gate_stride != 0;        // wave-uniform: one modulation row per sequence, else one for all
+      const int nq = nb0 + c16 * 4;
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m_blk = m0 + mt * 32;
+        const uint32_t area = st_base + (mt & 1) * 2048;
+        size_t goff = 0;
+        if (per_seq) {
+          int b = ((FULL || m_blk + lr < p.M) ? m_blk + lr : p.M - 1) / p.L;
+          if (b > p.B - 1) b = p.B - 1;
+          goff = (size_t)b * p.gate_stride;
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) {
+            int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+            asm volatile("" : "+v"(n));   // opaque: the table loads of the four blocks are not merged and kept live
+            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+            const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + goff + n);
+            const f32x4_t v = {rn_mul(acc[nt][mt][4 * g + 0] + b4.x, g4.x), rn_mul(acc[nt][mt][4 * g + 1] + b4.y, g4.y),
+                               rn_mul(acc[nt][mt][4 * g + 2] + b4.z, g4.z), rn_mul(acc[nt][mt][4 * g + 3] + b4.w, g4.w)};
+            lds_write16(wbase + (((nt * 8 + 2 * g + lh) ^ (lr & 7)) << 4), v);
+          }
+        float* cp = reinterpret_cast<float*>(p.C) + (size_t)(m_blk + r4) * p.ldc + nq;
+        const float* xp = p.xin + (size_t)(m_blk + r4) * p.ldc + nq;
+        f32x4_t xs[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          size_t ro = (size_t)(i * 4) * p.ldc;
+          if (!FULL && m_blk + i * 4 + r4 > p.M - 1) ro = 0;   // any valid row: the value is not stored
+          xs[i] = __builtin_nontemporal_load(reinterpret_cast<const f32x4_t*>(xp + ro));
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+          const uint32_t hb = hf ? h1 : h0;
+          f32x4_t o[4];
+          lds_read4(o, hb + k0, hb + 1024 + k1, hb + 2048 + k0, hb + 3072 + k1);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int i = hf * 4 + j;
+            const f32x4_t x4 = xs[i];
+            const f32x4_t v = {rn_add(x4.x, o[j].x), rn_add(x4.y, o[j].y), rn_add(x4.z, o[j].z), rn_add(x4.w, o[j].w)};
+            xs[i] = v;
+            if (FULL || m_blk + i * 4 + r4 < p.M) __builtin_nontemporal_store(v, reinterpret_cast<f32x4_t*>(cp + (size_t)(i * 4) * p.ldc));
+            float m_s, q_s;
+            lns_segment(v.x, v.y, v.z, v.w, m_s, q_s);
+            u32x2_t w2;
+            w2.x = __float_as_uint(m_s); w2.y = __float_as_uint(q_s);
+            if (c16 == 0) lds_write8(area + ((wave * 32 + i * 4 + r4) << 3), w2);
+          }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        float mean_r, rstd_r;   // of row lr of the block (both halves of the wave compute the same 32 rows)
+        {
+          f32x2_vt pw[8];
+          lds_read8x8_s256(pw, area + (lr << 3));
+          float ms[8], qs[8];
+#pragma unroll
+          for (int s8 = 0; s8 < 8; ++s8) { ms[s8] = pw[s8].x; qs[s8] = pw[s8].y; }
+          lns_combine8(ms, qs, p.ln_eps, mean_r, rstd_r);
+        }
+        const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(p.ln_w + nq);
+        bf16_t* op = p.ln_out + (size_t)(m_blk + r4) * p.N + nq;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          const int m = m_blk + i * 4 + r4;
+          const float mean = __int_as_float(__builtin_amdgcn_ds_bpermute((i * 4 + r4) << 2, __float_as_int(mean_r)));
+          const float rstd = __int_as_float(__builtin_amdgcn_ds_bpermute((i * 4 + r4) << 2, __float_as_int(rstd_r)));
+          size_t moff = 0;
+          if (per_seq) {
+            int b = ((FULL || m < p.M) ? m : p.M - 1) / p.L;
+            if (b > p.B - 1) b = p.B - 1;
+            moff = (size_t)b * p.gate_stride;
+          }
+          const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(p.ln_scale + moff + nq);
+          const f32x4_t s4 = *reinterpret_cast<const f32x4_t*>(p.ln_shift + moff + nq);
+          const f32x4_t v = xs[i];
+          u32x2_t pk;
+          pk.x = pack_bf16x2(lns_modulate(v.x, mean, rstd, w4.x, c4.x, s4.x), lns_modulate(v.y, mean, rstd, w4.y, c4.y, s4.y));
+          pk.y = pack_bf16x2(lns_modulate(v.z, mean, rstd, w4.z, c4.z, s4.z), lns_modulate(v.w, mean, rstd, w4.w, c4.w, s4.w));
+          if (FULL || m < p.M) *reinterpret_cast<u32x2_t*>(op + (size_t)(i * 4) * p.N) = pk;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __builtin_amdgcn_s_barrier();   // every wave has read its last statistics: the slot may be refilled
     } else if constexpr (LNG) {
       // bias, then LayerNorm over the 512 outputs of each row, affine, exact GELU, bf16.  A lane holds 32 of a row's
       // values per mt (its partner lane ^ 32 the other 32 of the wave's 64 columns), the other seven waves the rest.
@@ -851,8 +996,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
    for (int kt = 0; kt < nk - 1; ++kt) step(kt, std::false_type{});
    step(nk - 1, std::true_type{});
   }
-  if constexpr (LNG) {
-    // the epilogue holds two barriers of its own: group 0 runs the last one where every other one runs, right after the
+  if constexpr (ROWSTAT) {
+    // the epilogue holds barriers of its own: group 0 runs the last one where every other one runs, right after the
     // tile's last barrier pair and BEFORE its balancing barrier, so that its barriers pair with group 1's epilogue
     // (which ran at the end of group 1's last M phase); same free slot as group 1 used (slot(e) = slot + D)
     if (grp == 0) {
@@ -907,13 +1052,15 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   if (!attr_set) {
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, false, CFG, ROPE_LDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
-    SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, true, CFG, ROPE_LDS>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
+    if constexpr (EPI != EPI_GATE_RES_LN)   // (no convolution ends in a gated residual)
+      SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, true, CFG, ROPE_LDS>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     attr_set = true;
   }
-  if (sg.n_seg > 1)
-    hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
-  else
+  if (sg.n_seg > 1) {
+    if constexpr (EPI == EPI_GATE_RES_LN) return SGPO_ERR_UNSUPPORTED;
+    else hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
+  } else
     hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
@@ -952,13 +1099,18 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
   const bool big = tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096 && p.ldc % 4 == 0;
   if (epi == EPI_LN_GELU && (p.N != 512 || !p.ln_w || !p.ln_b || ((p.M + 127) / 128) < n_cu / 2)) return SGPO_ERR_UNSUPPORTED;
-  ProfScope prof_scope(epi == EPI_LN_GELU ? PK_GEMM_LN_GELU : PK_GEMM_BF16 + epi, stream, 2.0 * p.M * p.N * p.K);
+  if (epi == EPI_GATE_RES_LN && (p.N != 512 || p.ldc != 512 || !p.ln_w || !p.ln_shift || !p.ln_scale || !p.ln_out || !p.xin || !p.gate ||
+                                 ((p.M + 127) / 128) < n_cu / 2))
+    return SGPO_ERR_UNSUPPORTED;
+  ProfScope prof_scope(epi == EPI_LN_GELU ? PK_GEMM_LN_GELU : epi == EPI_GATE_RES_LN ? PK_GEMM_GATE_RES_LN : PK_GEMM_BF16 + epi, stream,
+                       2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;
 #ifdef SGPO_GEMM_ABLATE
   if (tile_mode == 2 && epi == EPI_GATE_RES && p.N == 512)   // K loop of the full-row tile, no epilogue (bit 4 forced)
     return launch_cfg<EPI_GATE_RES, CfgRow>(q, sg, zero16, n_cu, dbg | 4, stream);
 #endif
   if (epi == EPI_LN_GELU) return launch_cfg<EPI_LN_GELU, CfgRow>(q, sg, zero16, n_cu, dbg, stream);
+  if (epi == EPI_GATE_RES_LN) return launch_cfg<EPI_GATE_RES_LN, CfgRow>(q, sg, zero16, n_cu, dbg, stream);
 #define LAUNCH_BOTH(E)                                                              \
   case E:                                                                           \
     if (big) rc = launch_cfg<E, CfgBig>(q, sg, zero16, n_cu, dbg, stream);          \
@@ -999,4 +1151,15 @@ int launch_gemm_ln_gelu(const GemmParams& p, int n_seg, int seg_k, const int* sh
   const int rc = gemm_get_zero16(&z);
   if (rc) return rc;
   return launch_gemm_persistent(p, EPI_LN_GELU, sg, z, stream);
+}
+
+int launch_gemm_gate_res_ln(const GemmParams& p, hipStream_t stream) {
+  if (p.M <= 0 || p.K <= 0 || p.K % 64 != 0 || p.lda % 8 != 0 || p.ldw % 8 != 0 || p.L <= 0) return SGPO_ERR_UNSUPPORTED;
+  GemmSeg sg;
+  sg.n_seg = 1; sg.seg_k = p.K;
+  for (int i = 0; i < 8; ++i) sg.shift[i] = 0;
+  const bf16_t* z = nullptr;
+  const int rc = gemm_get_zero16(&z);
+  if (rc) return rc;
+  return launch_gemm_persistent(p, EPI_GATE_RES_LN, sg, z, stream);
 }

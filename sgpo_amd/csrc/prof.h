@@ -8,7 +8,7 @@
 enum ProfKind {
   PK_GEMM_BF16 = 0, PK_GEMM_QKV_ROPE, PK_GEMM_GATE_RES, PK_GEMM_BIAS_GELU, PK_GEMM_BIAS_F32, PK_GEMM_GELU_ERF,
   PK_GEMM_RES, PK_GEMM_ACC, PK_ATTENTION, PK_LN_MOD, PK_EMBED, PK_REVERSE_STEP, PK_MLP_BASE, PK_MLP_JUMP,
-  PK_D3PM_POSTERIOR, PK_DAPS_MH, PK_MISC, PK_FITNESS, PK_GEMM_LN_GELU, PK_COUNT
+  PK_D3PM_POSTERIOR, PK_DAPS_MH, PK_MISC, PK_FITNESS, PK_GEMM_LN_GELU, PK_GEMM_GATE_RES_LN, PK_COUNT
 };
 
 bool prof_on();

@@ -67,6 +67,6 @@ extern "C" const char* sgpo_prof_kind_name(int kind) {
       "gemm_bf16_kernel<EPI_BIAS_GELU>", "gemm_bf16_kernel<EPI_BIAS_F32>", "gemm_bf16_kernel<EPI_BIAS_GELU_ERF>",
       "gemm_bf16_kernel<EPI_RES>", "gemm_bf16_kernel<EPI_ACC_F32>", "attention_kernel", "ln_mod_kernel",
       "embed_kernel", "reverse_step_kernel", "mlp_base_kernel", "mlp_jump_kernel", "d3pm_posterior_kernel",
-      "daps_mh_kernel", "misc", "fitness_member_kernel", "gemm_bf16_kernel<EPI_LN_GELU>"};
+      "daps_mh_kernel", "misc", "fitness_member_kernel", "gemm_bf16_kernel<EPI_LN_GELU>", "gemm_bf16_kernel<EPI_GATE_RES_LN>"};
   return (kind >= 0 && kind < PK_COUNT) ? names[kind] : "?";
 }

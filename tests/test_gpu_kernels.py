@@ -114,6 +114,30 @@ def test_dit_forward_long_sequences(rt, dims, B, L):
     assert torch.equal(one[0], logits[B - 1])
 
 
+@pytest.mark.parametrize('per_seq', [True, False])
+def test_dit_forward_fused_residual_layernorm_is_bit_identical(rt, monkeypatch, per_seq):
+    """M = 137 x 119 = 16303 rows (ragged last 128-row tile): the out-projection and fc2 GEMMs take the full-row persistent
+    kernel whose epilogue also does the LayerNorm-modulate that follows (gemm_p.hip EPI_GATE_RES_LN).  The separate pass
+    (SGPO_DIT_FUSED_LN=0) and the fused kernel share one summation order (csrc/ln_stats.h): every logit and every hidden
+    value must be equal bit for bit -- with one modulation row per sequence and with one for the whole batch -- and rows
+    of the big batch must equal the same sequences run as a small batch (64-row GEMM + separate pass)."""
+    from sgpo_amd import weights as W
+    sd = W.dit_synthetic_state(seed=21)
+    net = rt.DitDenoiser(sd)
+    g = torch.Generator().manual_seed(10)
+    B, Lq = 137, 119
+    x = torch.randint(0, 31, (B, Lq), generator=g).cuda()
+    sigma = (torch.rand(B, generator=g) * 3).cuda() if per_seq else torch.full((1,), 0.7).cuda()
+    fused, hf = net.forward(x, sigma, return_hidden=True)
+    monkeypatch.setenv('SGPO_DIT_FUSED_LN', '0')
+    plain, hp = net.forward(x, sigma, return_hidden=True)
+    monkeypatch.delenv('SGPO_DIT_FUSED_LN')
+    assert torch.isfinite(fused).all()
+    assert torch.equal(hf, hp) and torch.equal(fused, plain)
+    small = net.forward(x[130:133].contiguous(), sigma[130:133].contiguous() if per_seq else sigma)
+    assert torch.equal(small, fused[130:133])
+
+
 @pytest.mark.parametrize('B', [12, 36])     # M = 1428: 256x128 tiles only; M = 4284: 256x256 tiles with a ragged last tile
 def test_dit_forward_large_batch_uses_persistent_gemm(rt, B):
     """M = B*L >= 1024 routes every GEMM (all epilogues: RoPE, GELU, gate+residual, vocab head) through
