@@ -113,7 +113,8 @@ def gemm_algorithmic_bytes(kind, batch, L=119, h=512, ff=2048):
         return M * h * 2 + 3 * h * h * 2 + M * 3 * h * 2
     if 'GATE_RES' in kind:
         a = (M * h * 2 + h * h * 2 + M * ff * 2 + h * ff * 2) / 2
-        return a + 2 * M * h * 4 + batch * h * 4
+        ln = M * h * 2 if 'GATE_RES_LN' in kind else 0          # fused kernel also writes the bf16 LayerNorm-modulate rows
+        return a + 2 * M * h * 4 + batch * h * 4 + ln
     if 'BIAS_GELU' in kind:
         return M * h * 2 + h * ff * 2 + M * ff * 2
     return None
@@ -235,7 +236,7 @@ class _Config4:
                 'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate', 'global_batch': self.world * self.B,
                 'parallelism': f'{self.world} cells at a time (independent sampler calls + one all-gather of tokens)'}
 
-    def cpu_baseline(self, n_seq=2, n_steps=3):
+    def cpu_baseline(self, n_seq=8, n_steps=12):
         from oracle import nos as onos
         cores = min(os.cpu_count() or 1, 16)
         torch.set_num_threads(cores)

@@ -22,9 +22,10 @@ TRPB_RES = [117, 118, 119, 162, 166, 182, 183, 184, 185, 186, 227, 228, 230, 231
 L_TRPB, NUM_STEPS, ODE_STEPS, MH_STEPS = 389, 50, 20, 1000
 
 
-def cpu_baseline(sd, msd, n_seq=2):
-    """CPU restatement (oracle/, the reference's formulation) on a bounded sample: 2 ByteNet forwards + posteriors and
-    one 1000-proposal Metropolis-Hastings chain for n_seq sequences, scaled to the 50 x (19 + 1) calls of a run."""
+def cpu_baseline(sd, msd, n_seq=16, n_fwd=6):
+    """CPU restatement (oracle/, the reference's formulation) on a bounded sample (10-20 s of CPU work): n_fwd ByteNet
+    forwards + posteriors and one 1000-proposal Metropolis-Hastings chain for n_seq sequences, scaled to the
+    50 x (19 + 1) calls of a run."""
     from oracle import bytenet as obn
     from oracle import d3pm as od3pm
     from oracle import daps as odaps
@@ -37,11 +38,11 @@ def cpu_baseline(sd, msd, n_seq=2):
     Q_bar, Q = od3pm.q_random_schedule(S, 500)
     sigma = od3pm.sigma_from_qbar(Q_bar, S)
     t0 = time.perf_counter()
-    for t, tn in ((400, 380), (380, 360)):
+    for t, tn in [(400 - 20 * k, 380 - 20 * k) for k in range(n_fwd)]:
         e = torch.empty(n_seq * L_TRPB, S, dtype=torch.float64).exponential_(1, generator=g)
         logits = obn.bytenet_forward(sd, x, torch.tensor([t] * n_seq))
         x = od3pm.p_sample(logits, x, t, tn, Q, Q_bar, sigma, S, e=e)
-    t_fwd = (time.perf_counter() - t0) / 2
+    t_fwd = (time.perf_counter() - t0) / n_fwd
     pred = omlp.Predictor(msd, TRPB_RES)
     r_idx = torch.randint(0, len(TRPB_RES), (MH_STEPS, n_seq), generator=g)
     r_val = torch.randint(0, S, (MH_STEPS, n_seq), generator=g)
@@ -52,8 +53,8 @@ def cpu_baseline(sd, msd, n_seq=2):
     t_mh = time.perf_counter() - t0
     per_run = NUM_STEPS * ((ODE_STEPS - 1) * t_fwd + t_mh)
     return dict(value=n_seq / per_run, unit='sequences/s', cores=cores, kind='port',
-                sample='%d sequences: 2 denoiser forwards + posteriors (%.1f s each) and one 1000-proposal MH chain (%.1f s), '
-                       'torch-CPU fp32 oracle, scaled to 50 x (19 forwards + 1 chain)' % (n_seq, t_fwd, t_mh))
+                sample='%d sequences: %d denoiser forwards + posteriors (%.2f s each) and one 1000-proposal MH chain (%.2f s), '
+                       'torch-CPU fp32 oracle, scaled to 50 x (19 forwards + 1 chain)' % (n_seq, n_fwd, t_fwd, t_mh))
 
 
 def main():
