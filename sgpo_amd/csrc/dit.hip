@@ -223,7 +223,10 @@ extern "C" int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float*
   const float* xcur;
   bool xn_ready = false;   // w.xn already holds the final layer's LayerNorm-modulate of xcur
   if (!x_emb) {
-    rc = launch_embed(tokens, m->embed, w.x, M, H, c.vocab, st);
+    // embedding gather and the first block's LayerNorm-modulate in one pass where the width allows
+    rc = launch_embed_ln_mod(tokens, m->embed, c.vocab, w.x, m->blocks[0].norm1, w.mod, w.mod + H, mod_stride, w.xn, M, L, B, H, st);
+    const bool first_ln_done = rc == SGPO_OK;
+    if (rc == SGPO_ERR_UNSUPPORTED) rc = launch_embed(tokens, m->embed, w.x, M, H, c.vocab, st);
     if (rc) return rc;
     // out-projection / fc2 GEMM + gate + residual + the LayerNorm-modulate that follows in one kernel where the shape
     // allows (gemm_p.hip EPI_GATE_RES_LN: the separate HBM pass over the residual stream disappears); otherwise, or
@@ -244,7 +247,7 @@ extern "C" int sgpo_dit_forward(sgpo_dit* m, const int64_t* tokens, const float*
     for (int i = 0; i < c.n_blocks; ++i) {
       const DitBlockW& b = m->blocks[i];
       const float* mod = w.mod + (size_t)i * 6 * H;  // shift_msa, scale_msa, gate_msa, shift_mlp, scale_mlp, gate_mlp
-      if (i == 0) {   // (the later blocks' first LayerNorm rides on the fc2 GEMM of the block before)
+      if (i == 0 && !first_ln_done) {   // (the later blocks' first LayerNorm rides on the fc2 GEMM of the block before)
         rc = launch_ln_mod(w.x, b.norm1, mod, mod + H, mod_stride, w.xn, M, L, B, H, st);
         if (rc) return rc;
       }

@@ -89,19 +89,29 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
 // LN: no bias, eps 1e-5, fp32 statistics.  One wave per row of H = 512 (8 floats per lane),
 // two-pass mean/variance in registers.  HBM-bound: 4H read + 2H written per row.
 template <int H>
+// With `tok` the row is the embedding of token[row] (embed_kernel's gather, dit.py:292-299) and is also written to
+// x_out: the first LayerNorm of a forward then costs no read of the residual stream.
 __global__ __launch_bounds__(256) void ln_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                      const float* __restrict__ shift, const float* __restrict__ scale,
-                                                     int mod_stride, bf16_t* __restrict__ out, int M, int L, int B) {
+                                                     int mod_stride, bf16_t* __restrict__ out, int M, int L, int B,
+                                                     const int64_t* __restrict__ tok, int vocab, float* __restrict__ x_out) {
   constexpr int PER = H / 64;  // floats per lane
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= M) return;
   const int lane = threadIdx.x & 63;
   float v[PER];
   const float* xr = x + (size_t)row * H;
+  if (tok) {
+    int64_t t = tok[row];
+    if (t < 0) t = 0;
+    if (t >= vocab) t = vocab - 1;
+    xr = x + (size_t)t * H;   // x is the embedding table here
+  }
 #pragma unroll
   for (int i = 0; i < PER / 4; ++i) {
     float4 t = reinterpret_cast<const float4*>(xr)[i * 64 + lane];
     v[i * 4 + 0] = t.x; v[i * 4 + 1] = t.y; v[i * 4 + 2] = t.z; v[i * 4 + 3] = t.w;
+    if (tok) reinterpret_cast<float4*>(x_out + (size_t)row * H)[i * 64 + lane] = t;
   }
   float mean, rstd;
   if constexpr (H == 512) {
@@ -176,9 +186,9 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
   dim3 grid((M + 3) / 4), block(256);
   ProfScope prof_scope(PK_LN_MOD, stream, (double)M * H * 6.0);  // 4H read + 2H written
   if (H == 512 && shift && scale)
-    hipLaunchKernelGGL(ln_mod_kernel<512>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B);
+    hipLaunchKernelGGL(ln_mod_kernel<512>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B, nullptr, 0, nullptr);
   else if (H == 1024 && shift && scale)
-    hipLaunchKernelGGL(ln_mod_kernel<1024>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B);
+    hipLaunchKernelGGL(ln_mod_kernel<1024>, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B, nullptr, 0, nullptr);
   else
     hipLaunchKernelGGL(ln_mod_generic_kernel, grid, block, 0, stream, x, w, shift, scale, mod_stride, out, M, L, B, H);
   SGPO_CHECK_HIP(hipGetLastError());
@@ -406,6 +416,20 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
 int launch_embed(const int64_t* tok, const float* emb, float* x, int M, int H, int vocab, hipStream_t stream) {
   ProfScope prof_scope(PK_EMBED, stream, (double)M * (H * 4.0 + 8.0));   // fp32 row written, one int64 token read (the table stays in cache)
   hipLaunchKernelGGL(embed_kernel, dim3((M + 3) / 4), dim3(256), 0, stream, tok, emb, x, M, H, vocab);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// embedding gather + the first LayerNorm-modulate in one pass (H = 512 / 1024); SGPO_ERR_UNSUPPORTED otherwise
+int launch_embed_ln_mod(const int64_t* tok, const float* emb, int vocab, float* x, const float* w, const float* shift,
+                        const float* scale, int mod_stride, bf16_t* out, int M, int L, int B, int H, hipStream_t stream) {
+  if ((H != 512 && H != 1024) || !shift || !scale) return SGPO_ERR_UNSUPPORTED;
+  dim3 grid((M + 3) / 4), block(256);
+  ProfScope prof_scope(PK_EMBED, stream, (double)M * (H * 6.0 + 8.0));   // fp32 row + bf16 row written, one token read
+  if (H == 512)
+    hipLaunchKernelGGL(ln_mod_kernel<512>, grid, block, 0, stream, emb, w, shift, scale, mod_stride, out, M, L, B, tok, vocab, x);
+  else
+    hipLaunchKernelGGL(ln_mod_kernel<1024>, grid, block, 0, stream, emb, w, shift, scale, mod_stride, out, M, L, B, tok, vocab, x);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
