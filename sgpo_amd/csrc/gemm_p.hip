@@ -50,12 +50,6 @@ struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NS
 struct CfgRow { static constexpr int WM = 1, WN = 8, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
 template <typename C> struct is_row_cfg : std::is_same<C, CfgRow> {};
 
-#ifndef RLN_V
-#define RLN_V 0
-#endif
-#ifndef LNG_V
-#define LNG_V 2
-#endif
 enum { PF_EXACT = 1 };
 #define LDS_MAX_BYTES 163840
 
@@ -643,11 +637,6 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       // ([wave][mt][row] float2, 8 KiB): written, barrier, read by every wave, barrier (the next prefetch overwrites
       // it).  Both wave groups run their epilogue in the same barrier interval, so the two extra barriers pair up.
       const uint32_t st_base = lds_addr(smem + fslot * STAGE);
-#if LNG_V >= 3
-      int te = tid;
-      asm volatile("" : "+v"(te));   // lane-derived values of the epilogue come from the thread id here, not from registers carried through the K loop
-      const int lr = te & 31, lh = (te >> 5) & 1;
-#endif
       // (the accumulators are only read: acc + bias is formed again in each of the three passes, from L1/L2-resident
       //  bias quads -- updating them in place made the register allocator keep a second copy and spill)
       float mean[MT], rstd[MT];
@@ -729,14 +718,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               v[q] = epi_gelu_erf_fast(fmaf(rn_mul((acc[nt][mt][4 * g + q] + bv[q]) - mean[mt], rstd[mt]), wv[q], cv[q]));
-#if LNG_V == 1
-              __builtin_amdgcn_sched_barrier(0);
-#endif
             }
             block_put(h0, h1, nt, g, pack4(v[0], v[1], v[2], v[3]), lr, lh);
-#if LNG_V != 2 && LNG_V != 3
-            __builtin_amdgcn_sched_barrier(0);   // one quad at a time beside 128 accumulators
-#endif
           }
         block_flush(h0, h1, m_blk, nb0, full_tag);
         __builtin_amdgcn_sched_barrier(0);
