@@ -48,7 +48,15 @@ struct CfgRes { static constexpr int WM = 4, WN = 2, MT = 2, NT = 2, BK = 64, NS
 // Operand traffic per flop is 1.25x that of 256x256; the K loop alone measured 647 vs 608 us on the out-proj/fc2 shapes
 // (DESIGN.md section 6).  No LDS is left for the bias table: bias and the LayerNorm affine come from global memory (L2).
 struct CfgRow { static constexpr int WM = 1, WN = 8, MT = 4, NT = 2, BK = 64, NST = 2, PH = 2; };
+#ifdef SGPO_GEMM_ABLATE
+// Diagnostic build only (SGPO_GEMM_TILE=h): 64 x 512 tile, K loop only.  Its accumulators are 64 registers per lane, so two
+// tiles could be in flight per wave (the epilogue of one sliced into the K steps of the next); this prices the K loop
+// of such a design: 2.25x the operand bytes per flop of 256 x 256.
+struct CfgHalf { static constexpr int WM = 1, WN = 8, MT = 2, NT = 2, BK = 64, NST = 2, PH = 2; };
+template <typename C> struct is_row_cfg : std::integral_constant<bool, std::is_same<C, CfgRow>::value || std::is_same<C, CfgHalf>::value> {};
+#else
 template <typename C> struct is_row_cfg : std::is_same<C, CfgRow> {};
+#endif
 
 enum { PF_EXACT = 1 };
 #define LDS_MAX_BYTES 163840
@@ -200,6 +208,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr int A_BYTES = BM * ROWB, B_BYTES = BN * ROWB, STAGE = A_BYTES + B_BYTES;
   constexpr int A_PW = A_BYTES / 8192, B_PW = B_BYTES / 8192, OPS = A_PW + B_PW, D = NST - 1;
   constexpr int PH = CFG::PH, KP = KK / PH;
+  constexpr bool ROW_CFG_ANY = is_row_cfg<CFG>::value;
   constexpr bool RLN = (EPI == EPI_GATE_RES_LN);
   constexpr bool RES = (EPI == EPI_GATE_RES || EPI == EPI_RES || RLN);
   constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
@@ -218,7 +227,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   constexpr bool ROWSTAT = LNG || RLN;   // the epilogue exchanges row statistics between the waves (barriers of its own)
   constexpr int E_ST = STAGED32 ? MT * 8 : (PRE || F32OUT) ? MT * NT * 4 : MT * 4;
   static_assert(WM * WN == 8 && A_PW * 8192 == A_BYTES && B_PW * 8192 == B_BYTES, "tile / wave layout");
-  static_assert(NT == 2 && A_PW >= 2 && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
+  static_assert(NT == 2 && (A_PW >= 2 || ROW_CFG_ANY) && B_PW >= 2, "bf16 output staging: 32 x 64 block = two 2-KiB halves");
   static_assert(OPS * (D - 1) + E_ST < 64, "vmcnt range");
   static_assert(!STAGED32 || (A_PW >= 4 && B_PW >= 4) || ROW, "fp32 output staging: 32 x 64 block = two 4-KiB halves");
 
@@ -286,7 +295,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // the whole launch, so staging a full tile costs one scalar base per operand + OPS DMA instructions
   // (pieces j and j + 2 of an operand are 16 rows apart and share the swizzle term, so two offsets per operand and a
   //  scalar row stride describe them all)
-  static_assert(CH == 8 && A_PW % 2 == 0 && B_PW % 2 == 0, "piece offsets: 128-B rows, pairs of pieces");
+  static_assert(CH == 8 && (A_PW % 2 == 0 || A_PW == 1) && B_PW % 2 == 0, "piece offsets: 128-B rows, pairs of pieces");
   uint32_t a_off[2], w_off[2];
 #pragma unroll
   for (int j = 0; j < 2; ++j) {
@@ -1069,7 +1078,7 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   }
   if (tile_mode < 0) {
     const char* e = getenv("SGPO_GEMM_TILE");   // "s": always the 256x128 tile (A/B measurements)
-    tile_mode = (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : 0;
+    tile_mode = (e && e[0] == 's') ? 1 : (e && e[0] == 'r') ? 2 : (e && e[0] == 'h') ? 3 : 0;
   }
 #ifdef SGPO_GEMM_ABLATE
   { const char* e = getenv("SGPO_GEMM_DBG"); dbg = e ? atoi(e) : 0; }
@@ -1091,6 +1100,10 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #ifdef SGPO_GEMM_ABLATE
   if (tile_mode == 2 && epi == EPI_GATE_RES && p.N == 512)   // K loop of the full-row tile, no epilogue (bit 4 forced)
     return launch_cfg<EPI_GATE_RES, CfgRow>(q, sg, zero16, n_cu, dbg | 4, stream);
+  if (tile_mode == 3 && (epi == EPI_GATE_RES || epi == EPI_BIAS_GELU) && p.N % 512 == 0) {   // K loop of the 64 x 512 tile
+    if (epi == EPI_GATE_RES) return launch_cfg<EPI_GATE_RES, CfgHalf>(q, sg, zero16, n_cu, dbg | 4, stream);
+    return launch_cfg<EPI_BIAS_GELU, CfgHalf>(q, sg, zero16, n_cu, dbg | 4, stream);
+  }
 #endif
   if (epi == EPI_LN_GELU) return launch_cfg<EPI_LN_GELU, CfgRow>(q, sg, zero16, n_cu, dbg, stream);
   if (epi == EPI_GATE_RES_LN) return launch_cfg<EPI_GATE_RES_LN, CfgRow>(q, sg, zero16, n_cu, dbg, stream);
