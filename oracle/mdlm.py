@@ -137,19 +137,29 @@ def get_all_jump_transitions(x, S):
     return xj
 
 
-def get_guided_rates(predictor, x, t, q_t, S, guide_temp=1.0):
-    """Exact-guidance branch of get_guided_rates (mdlm.py:340-413, d3pm.py:109-199).
+def get_guided_rates(predictor, x, t, q_t, S, guide_temp=1.0, use_tag=False):
+    """get_guided_rates (mdlm.py:340-413, d3pm.py:109-199), exact branch and (use_tag) the first-order Taylor branch.
 
-    predictor(x (N,D), t (N,)) -> (N,1).  Returns (q_t * ratio, log_ratio_scaled_clamped).
+    exact: predictor(x (N,D), t (N,)) -> (N,1) on every materialised single-site jump.
+    TAG (mdlm.py:377-394): predictor(one-hot (N,D,S) float, t) is differentiated at the one-hot point; the estimate of
+    the jump (d, s) is grad[d, s] - grad[d, x_d].
+    Returns (q_t * ratio, log_ratio_scaled_clamped).
     """
     if guide_temp == 0:
         return q_t, None
     B, D = x.shape
     tt = t * torch.ones((B,))
-    lp = predictor(x, tt)
-    xj = get_all_jump_transitions(x, S)
-    lpj = predictor(xj, tt.repeat(1, D * S).flatten()).view(B, D, S)
-    lr = lpj - lp.view(B, 1, 1)
+    if use_tag:
+        onehot = torch.nn.functional.one_hot(x.long(), S).float()
+        with torch.enable_grad():
+            point = onehot.clone().requires_grad_(True)
+            (grad,) = torch.autograd.grad(predictor(point, tt).sum(), point)
+        lr = grad - (grad * onehot).sum(-1, keepdim=True)
+    else:
+        lp = predictor(x, tt)
+        xj = get_all_jump_transitions(x, S)
+        lpj = predictor(xj, tt.repeat(1, D * S).flatten()).view(B, D, S)
+        lr = lpj - lp.view(B, 1, 1)
     lr = lr / guide_temp
     lr = torch.clamp(lr, max=80)
     q = q_t * torch.exp(lr)

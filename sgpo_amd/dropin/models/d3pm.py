@@ -127,10 +127,11 @@ class D3PM(GenerativeModel):
         predictor is the MLP value function."""
         if guide_temp == 0:
             return q_t
-        if use_tag:
-            raise NotImplementedError('TAG guidance is never enabled by the reference callers (SURVEY a-5)')
-        vf = getattr(predictor_model, 'hip_value_function', None)
-        if vf is not None:
+        vf = None if use_tag else getattr(predictor_model, 'hip_value_function', None)
+        if use_tag:       # first-order estimate from one gradient (never enabled by the reference's callers)
+            from ._tag import taylor_log_ratios
+            lr = taylor_log_ratios(predictor_model, x, t, self.S)
+        elif vf is not None:
             vf = vf()
             lr_c = vf.jump_log_ratios(x, float(t), self.S)
             slots = _slot_map(vf.read_pos, x.shape[1], x.device)

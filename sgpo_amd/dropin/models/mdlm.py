@@ -224,16 +224,19 @@ class MDLM(GenerativeModel):
 
     def get_guided_rates(self, predictor_model, x, t, q_t, use_tag=False, guide_temp=1.0,
                          log_prob_ratio_cutoff=80.0):
-        """Exact classifier-guided rates (models/mdlm.py:340-413).
+        """Classifier-guided rates (models/mdlm.py:340-413): exact jump ratios, or their Taylor estimate with use_tag.
 
         The sampling loop does not call this: `Classifier_Guidance_Inpaint.inference` uses the
         fused kernel.  This entry point keeps the reference signature for other callers.
         """
         if guide_temp == 0:
             return q_t
-        if use_tag:
-            raise NotImplementedError('TAG guidance is never enabled by the reference callers (SURVEY a-5)')
-        lr, slots = self._jump_log_ratios(predictor_model, x, t)
+        slots = None
+        if use_tag:       # first-order estimate from one gradient (never enabled by the reference's callers)
+            from ._tag import taylor_log_ratios
+            lr = taylor_log_ratios(predictor_model, x, t, self.S)
+        else:
+            lr, slots = self._jump_log_ratios(predictor_model, x, t)
         if slots is not None:
             full = torch.zeros(x.shape[0], x.shape[1], self.S, dtype=torch.float32, device=x.device)
             pos = torch.nonzero(slots >= 0).squeeze(-1)

@@ -55,7 +55,12 @@ class MLPModel(nn.Module):
         """Autograd-capable torch forward: used for training (out of the sampling hot path)."""
         if self.residues is not None:
             seq = seq[:, self.residues]
-        seq_encoded = F.one_hot(seq.long(), num_classes=self.alphabet_size).float()
+        if seq.dim() == 3:
+            # rows that are already one-hot (B, D, S <= alphabet): the Taylor-guidance branch differentiates through them
+            # (models/mdlm.py:377-394; the reference one-hots them a second time here and fails)
+            seq_encoded = F.pad(seq.float(), (0, self.alphabet_size - seq.shape[-1]))
+        else:
+            seq_encoded = F.one_hot(seq.long(), num_classes=self.alphabet_size).float()
         feat = self.embedder(seq_encoded)
         if self.time_conditioned:
             time_embed = self.time_embedder(t)
@@ -100,7 +105,7 @@ class ProteinPredictor(nn.Module):
 
     def __call__(self, inputs, t):
         """inputs (B, D), t (B) -> (B, 1)."""
-        if not torch.is_grad_enabled() and not self.model.training and inputs.is_cuda:
+        if not torch.is_grad_enabled() and not self.model.training and inputs.is_cuda and inputs.dim() == 2:
             tt = torch.as_tensor(t, dtype=torch.float32, device=inputs.device)
             return self.hip_value_function().forward(inputs, tt).unsqueeze(-1)
         return self.model(inputs, t)

@@ -170,6 +170,34 @@ def test_get_guided_rates_signature(env):
     assert net.get_guided_rates(pred, xs, 9, q, guide_temp=0) is q
 
 
+def test_get_guided_rates_taylor_branch(env):
+    """`use_tag=True` (models/mdlm.py:377-394) through the drop-in: against the reference's own branch run with a value
+    function that takes one-hot rows (golden `tag_small`), and with the drop-in `ProteinPredictor`, whose MLPModel accepts
+    one-hot rows (the reference's does not), against torch autograd on the CPU copy of the same weights.  D3PM shares
+    the helper: its estimate for a predictor that is linear in the one-hot rows equals its exact jump ratios."""
+    from oracle import mdlm as omdlm
+    from oracle.toy_predictor import OneHotToy
+    g = load_golden('tag_small')
+    gs = load_golden('cg_small_guided')
+    T = int(g['T'])
+    xs = g['xs']
+    Lq = xs.shape[1]
+    full_seq = bytes(gs['full_seq'].numpy().tolist()).decode()
+    net, pred, algo, sd, msd = _build(gs, T, Lq, full_seq, 0.5, int(gs['mlp_seed']))
+    toy = OneHotToy(Lq, 31, seed=int(g['toy_seed'])).cuda()
+    for temp, key in zip(g['temps'].tolist(), ('qg_a', 'qg_b')):
+        qg = net.get_guided_rates(toy, xs.cuda(), torch.tensor(9), g['q'].cuda().clone(), use_tag=True, guide_temp=temp)
+        torch.testing.assert_close(qg.cpu(), g[key], rtol=1e-4, atol=1e-9)
+    # the shipped predictor class: gradient through MLPModel at the one-hot point
+    qg = net.get_guided_rates(pred, xs.cuda(), torch.tensor(9), g['q'].cuda().clone(), use_tag=True, guide_temp=0.5)
+    import copy
+    cpu_model = copy.deepcopy(pred.model).cpu()
+    ref, _ = omdlm.get_guided_rates(lambda x1h, t: cpu_model(x1h, t), xs, torch.tensor(9), g['q'].clone(), 31, guide_temp=0.5,
+                                    use_tag=True)
+    torch.testing.assert_close(qg.cpu(), ref.detach(), rtol=1e-4, atol=1e-9)
+    assert not torch.equal(qg.cpu(), g['q'])
+
+
 @pytest.mark.parametrize('name', ['mdlm_sample_small', 'mdlm_sample_real'])
 def test_mdlm_sample_uncond_teacher_forced(env, name):
     """Row a-15, `MDLM.sample` (Uncond path; mdlm_diffusion.py:634-700), walked along the REFERENCE's own states (golden

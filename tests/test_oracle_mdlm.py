@@ -162,3 +162,22 @@ def test_cls_guidance_config1_first_rows_teacher_forced():
         x_next, _ = ocg.cg_step(q, states[i], lambda qm: qm, es[i])
         want = states[i + 1] if i + 1 < T - 1 else g['x'][:n]
         assert torch.equal(x_next, want), f'step {i}'
+
+
+def test_taylor_guided_rates_against_reference():
+    """The TAG branch of get_guided_rates (models/mdlm.py:377-394): golden = the reference's own branch run with a value
+    function that takes one-hot rows (oracle/toy_predictor.py); the restatement must reproduce it."""
+    from oracle.toy_predictor import OneHotToy
+    g = load_golden('tag_small')
+    xs, q = g['xs'], g['q']
+    toy = OneHotToy(xs.shape[1], 31, seed=int(g['toy_seed']))
+    for temp, key in zip(g['temps'].tolist(), ('qg_a', 'qg_b')):
+        qg, _ = omdlm.get_guided_rates(toy, xs, torch.tensor(9), q.clone(), 31, guide_temp=temp, use_tag=True)
+        torch.testing.assert_close(qg.detach(), g[key], rtol=1e-5, atol=1e-9)
+    # for a value function that is LINEAR in the one-hot rows the first-order estimate is the exact jump ratio
+    w = torch.randn(xs.shape[1] * 31, generator=torch.Generator().manual_seed(2)) * 0.1
+    lin_onehot = lambda x1h, t: (x1h.flatten(1) @ w)[:, None]
+    lin_tokens = lambda x, t: lin_onehot(torch.nn.functional.one_hot(x.long(), 31).float(), t)
+    a, _ = omdlm.get_guided_rates(lin_onehot, xs, torch.tensor(9), q.clone(), 31, guide_temp=0.7, use_tag=True)
+    b, _ = omdlm.get_guided_rates(lin_tokens, xs, torch.tensor(9), q.clone(), 31, guide_temp=0.7)
+    torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-8)

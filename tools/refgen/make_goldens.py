@@ -241,6 +241,26 @@ def gen_cg():
              full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
 
 
+def gen_tag():
+    """get_guided_rates(use_tag=True) of the reference MDLM wrapper with a value function that takes one-hot rows
+    (oracle/toy_predictor.py; the shipped MLPModel cannot run this branch)."""
+    from oracle.toy_predictor import OneHotToy
+    B, L, T = 3, 24, 16
+    net, core, sd = build_ref_mdlm(SMALL, seed=15, L=L, T=T)
+    toy = OneHotToy(L, 31, seed=41)
+    g = torch.Generator().manual_seed(5)
+    xs = torch.randint(0, 26, (B, L), generator=g)
+    xs[:, ::4] = 28
+    with torch.no_grad():
+        q = net.p_sample(xs, torch.tensor(9), hard=False)
+    out = {}
+    for temp in (0.5, 0.064):
+        qg = net.get_guided_rates(toy, xs, torch.tensor(9), q.clone(), use_tag=True, guide_temp=temp)
+        out[f'qg_{temp}'] = qg.detach()
+    save('tag_small', seed=15, toy_seed=41, dims=np.array(list(SMALL.values())), T=T, xs=xs, q=q, temps=np.array([0.5, 0.064]),
+         qg_a=out['qg_0.5'], qg_b=out['qg_0.064'])
+
+
 def gen_cg_real():
     """BASELINE configs 1/2 at full size: the real DiT dims, CreiLOV (L = 119), 127 reverse steps, temperature 0.064,
     B = 2.  The Exp(1) noise of torch.multinomial (3.7 MB) is not stored: the test redraws it from the same CPU
@@ -896,7 +916,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
