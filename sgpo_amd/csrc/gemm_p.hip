@@ -1089,7 +1089,16 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
 #endif
   GemmParams q = p;
   if (!q.bias) q.bias = reinterpret_cast<const float*>(zero16);
-  const bool big = tile_mode == 0 && p.N % 256 == 0 && p.M >= 4096 && p.ldc % 4 == 0;
+  // 256x256 or 256x128 tiles: a persistent launch takes ceil(tiles / CUs) rounds of one tile each, and a 256x128 tile
+  // costs 0.625 of a 256x256 one (half the flops at 1.25x the operand bytes per flop).  With many tiles the big tile
+  // wins (1.0 vs 1.25 per unit of work); at a few hundred sequences the round count decides (measured at B = 64 ... 800,
+  // tools/dbg/gemm_bench.py with SGPO_GEMM_TILE: the rule picks the faster tile in every case).  Same bits either way.
+  bool big = tile_mode == 0 && p.N % 256 == 0 && p.ldc % 4 == 0;
+  if (big) {
+    const long tm = (p.M + 255) / 256;
+    const long r_big = (tm * ((p.N + 255) / 256) + n_cu - 1) / n_cu, r_res = (tm * ((p.N + 127) / 128) + n_cu - 1) / n_cu;
+    big = 8 * r_big <= 5 * r_res;
+  }
   if (epi == EPI_LN_GELU && (p.N != 512 || !p.ln_w || !p.ln_b || ((p.M + 127) / 128) < n_cu / 2)) return SGPO_ERR_UNSUPPORTED;
   if (epi == EPI_GATE_RES_LN && (p.N != 512 || p.ldc != 512 || !p.ln_w || !p.ln_shift || !p.ln_scale || !p.ln_out || !p.xin || !p.gate ||
                                  ((p.M + 127) / 128) < n_cu / 2))
