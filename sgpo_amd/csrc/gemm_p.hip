@@ -1100,9 +1100,13 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
     big = 8 * r_big <= 5 * r_res;
   }
   if (epi == EPI_LN_GELU && (p.N != 512 || !p.ln_w || !p.ln_b || ((p.M + 127) / 128) < n_cu / 2)) return SGPO_ERR_UNSUPPORTED;
-  if (epi == EPI_GATE_RES_LN && (p.N != 512 || p.ldc != 512 || !p.ln_w || !p.ln_shift || !p.ln_scale || !p.ln_out || !p.xin || !p.gate ||
-                                 ((p.M + 127) / 128) < n_cu / 2))
-    return SGPO_ERR_UNSUPPORTED;
+  if (epi == EPI_GATE_RES_LN) {
+    if (p.N != 512 || p.ldc != 512 || !p.ln_w || !p.ln_shift || !p.ln_scale || !p.ln_out || !p.xin || !p.gate) return SGPO_ERR_UNSUPPORTED;
+    // worth it only when the 128-row tiles fill their rounds: measured against GEMM + separate pass at B = 137 ... 1600
+    // (L = 119), the fused kernel loses 4-15 % where the last round is mostly idle (fill 0.5-0.73) and wins from 0.79 up
+    const long tiles = (p.M + 127) / 128, rounds = (tiles + n_cu - 1) / n_cu;
+    if (tiles < 2 * n_cu || 4 * tiles < 3 * rounds * n_cu) return SGPO_ERR_UNSUPPORTED;
+  }
   ProfScope prof_scope(epi == EPI_LN_GELU ? PK_GEMM_LN_GELU : epi == EPI_GATE_RES_LN ? PK_GEMM_GATE_RES_LN : PK_GEMM_BF16 + epi, stream,
                        2.0 * p.M * p.N * p.K);
   int rc = SGPO_ERR_UNSUPPORTED;

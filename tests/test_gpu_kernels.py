@@ -116,26 +116,43 @@ def test_dit_forward_long_sequences(rt, dims, B, L):
 
 @pytest.mark.parametrize('per_seq', [True, False])
 def test_dit_forward_fused_residual_layernorm_is_bit_identical(rt, monkeypatch, per_seq):
-    """M = 137 x 119 = 16303 rows (ragged last 128-row tile): the out-projection and fc2 GEMMs take the full-row persistent
-    kernel whose epilogue also does the LayerNorm-modulate that follows (gemm_p.hip EPI_GATE_RES_LN).  The separate pass
-    (SGPO_DIT_FUSED_LN=0) and the fused kernel share one summation order (csrc/ln_stats.h): every logit and every hidden
-    value must be equal bit for bit -- with one modulation row per sequence and with one for the whole batch -- and rows
-    of the big batch must equal the same sequences run as a small batch (64-row GEMM + separate pass)."""
+    """M = 1075 x 119 = 127925 rows (1000 tiles of 128 rows, the last one ragged): the out-projection and fc2 GEMMs take the
+    full-row persistent kernel whose epilogue also does the LayerNorm-modulate that follows (gemm_p.hip EPI_GATE_RES_LN;
+    the launch counters confirm it ran).  The separate pass (SGPO_DIT_FUSED_LN=0) and the fused kernel share one summation
+    order (csrc/ln_stats.h): every logit and every hidden value must be equal bit for bit -- with one modulation row per
+    sequence and with one for the whole batch -- and rows of the big batch must equal the same sequences run as a small
+    batch (64-row GEMM + separate pass)."""
+    import ctypes as C
+    from sgpo_amd import _lib as L
     from sgpo_amd import weights as W
+    lib = L.load()
     sd = W.dit_synthetic_state(seed=21)
     net = rt.DitDenoiser(sd)
     g = torch.Generator().manual_seed(10)
-    B, Lq = 137, 119
+    B, Lq = 1075, 119
     x = torch.randint(0, 31, (B, Lq), generator=g).cuda()
     sigma = (torch.rand(B, generator=g) * 3).cuda() if per_seq else torch.full((1,), 0.7).cuda()
-    fused, hf = net.forward(x, sigma, return_hidden=True)
+
+    def fused_launches(fn):
+        L.check(lib.sgpo_prof_enable(1, 256), 'prof_enable')
+        out = fn()
+        torch.cuda.synchronize()
+        n = L.PROF_KINDS
+        ms, cnt, work = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+        L.check(lib.sgpo_prof_read(n, ms, cnt, work), 'prof_read')
+        lib.sgpo_prof_enable(0, 0)
+        by_name = {lib.sgpo_prof_kind_name(k).decode(): int(cnt[k]) for k in range(n)}
+        return out, by_name.get('gemm_bf16_kernel<EPI_GATE_RES_LN>', 0)
+
+    (fused, hf), n_fused = fused_launches(lambda: net.forward(x, sigma, return_hidden=True))
     monkeypatch.setenv('SGPO_DIT_FUSED_LN', '0')
-    plain, hp = net.forward(x, sigma, return_hidden=True)
+    (plain, hp), n_plain = fused_launches(lambda: net.forward(x, sigma, return_hidden=True))
     monkeypatch.delenv('SGPO_DIT_FUSED_LN')
+    assert n_fused == 16 and n_plain == 0
     assert torch.isfinite(fused).all()
     assert torch.equal(hf, hp) and torch.equal(fused, plain)
-    small = net.forward(x[130:133].contiguous(), sigma[130:133].contiguous() if per_seq else sigma)
-    assert torch.equal(small, fused[130:133])
+    small = net.forward(x[1070:1073].contiguous(), sigma[1070:1073].contiguous() if per_seq else sigma)
+    assert torch.equal(small, fused[1070:1073])
 
 
 @pytest.mark.parametrize('B', [12, 36])     # M = 1428: 256x128 tiles only; M = 4284: 256x256 tiles with a ragged last tile
