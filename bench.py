@@ -12,7 +12,7 @@ function scores over RCCL, as SURVEY.md section 8(e) lays out.
     python bench.py --gpus 1 --steps 2 --warmup 1
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
 
-`--config {2,3,4,5}` selects another BASELINE configuration for the same JSON line (2 is the default and the
+`--config {1,2,3,4,5}` selects another BASELINE configuration for the same JSON line (2 is the default and the
 driver's headline): 3 = D3PM + daps_discrete on TrpB, 2048 sequences per GPU (a bench step is ONE of the run's 50
 identical annealing steps, `value` is scaled to whole runs); 4 = MDLM + NOS_discrete on TrpB, one (strength, repeat)
 cell of 200 sequences per GPU and step; 5 = Thompson draws of 10 sequences, one ensemble member per GPU and step.
@@ -303,6 +303,49 @@ class _Config5(_Config4):
         return cpu_baseline(self.sd, self.msd, n_seq=10, n_steps=24)
 
 
+class _Config1(_Config5):
+    """prior_sample.py: unguided prior samples of the MDLM denoiser on CreiLOV (temperature 0), 64 sequences per call."""
+    default_batch = 64
+
+    def __init__(self, device, batch, rank, world):
+        self.B, self.rank, self.world = batch, rank, world
+        self.net, self.pred, self.algo, self.sd, self.msd = build(device, batch)
+        self.algo.temperature = 0.0
+
+    def step(self, i):
+        self.net.reseed(seed=2000 + i, row_offset=self.rank * self.B)
+        x = self.algo.inference(num_samples=self.B)
+        return x, self.pred.log_likelihood(x)
+
+    def describe(self):
+        return {'workload': 'MDLM prior sampling (cls_guidance_discrete at temperature 0) on CreiLOV, L=119, 127 reverse steps, '
+                            '%d sequences per GPU and bench step' % self.B,
+                'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate', 'global_batch': self.world * self.B,
+                'parallelism': f'dp{self.world} (independent shards + all-gather of tokens/scores)'}
+
+    def cpu_baseline(self):
+        """Unguided steps of the CPU restatement (one denoiser forward + reverse step each) on a bounded sample."""
+        from oracle import cls_guidance as ocg
+        from oracle import mdlm as omdlm
+        cores = min(os.cpu_count() or 1, 16)
+        torch.set_num_threads(cores)
+        n_seq, n_steps = 64, 12
+        gen = torch.Generator().manual_seed(7)
+        x = 28 * torch.ones((n_seq, 119), dtype=torch.int64)
+        ts = torch.linspace(T_STEPS - 1, 1, T_STEPS - 1, dtype=int)[:n_steps]
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            for t in ts:
+                q = omdlm.p_sample(self.sd, x, t, T_STEPS, 28, hard=False)
+                e = torch.empty(n_seq, 119, 31).exponential_(1, generator=gen)
+                x, _ = ocg.cg_step(q, x, lambda qm: qm, e)
+        dt = time.perf_counter() - t0
+        per_seq = dt / n_seq * (T_STEPS - 1) / n_steps
+        return dict(value=1.0 / per_seq, unit='sequences/s', cores=cores, kind='port',
+                    sample=f'{n_seq} sequences x {n_steps} of 127 unguided steps, torch-CPU fp32 oracle, {dt:.1f} s measured, '
+                           'scaled linearly to 127 steps')
+
+
 def _dist_init(world, local_rank):
     """One process per GPU over RCCL (`nccl`).  SGPO_BENCH_BACKEND=gloo is the rehearsal of the N > 1 control flow on a box
     with fewer GPUs than ranks (RCCL refuses two ranks on one device): ranks share the GPUs round-robin and the gathers are
@@ -339,7 +382,7 @@ def _max_over_ranks(dist, backend, dt, device):
 
 
 def main_other(a):
-    """Configs 3 / 4 / 5 through the bench contract: W warm-up steps, K timed steps between barrier + synchronize, max over
+    """Configs 1 / 3 / 4 / 5 through the bench contract: W warm-up steps, K timed steps between barrier + synchronize, max over
     ranks, one JSON line from rank 0 with `roofline` (dominant kernel, HIP events on the launch stream) and `cpu_baseline`."""
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
@@ -348,13 +391,13 @@ def main_other(a):
         raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     dist, device, backend = _dist_init(world, local_rank)
     from sgpo_amd import _lib as L
-    cls = {3: _Config3, 4: _Config4, 5: _Config5}[a.config]
+    cls = {1: _Config1, 3: _Config3, 4: _Config4, 5: _Config5}[a.config]
     wl = cls(device, a.batch or cls.default_batch, rank, world)
     lib = L.load()
 
     def one_step(i):
         x, sc = wl.step(i)
-        if world > 1 and a.config == 3:          # batch rows sharded: the all-gather of tokens (uint8) and scores
+        if world > 1 and a.config in (1, 3):     # batch rows sharded: the all-gather of tokens (uint8) and scores
             B = x.shape[0]
             all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
             all_s = torch.empty(world * B, dtype=torch.float32, device=device)
@@ -429,7 +472,7 @@ def main():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=2)
     ap.add_argument('--warmup', type=int, default=1)
-    ap.add_argument('--config', type=int, default=2, choices=[2, 3, 4, 5], help='BASELINE configuration (2 = headline)')
+    ap.add_argument('--config', type=int, default=2, choices=[1, 2, 3, 4, 5], help='BASELINE configuration (2 = headline)')
     ap.add_argument('--batch', type=int, default=None, help='sequences per GPU per step (default: the configuration\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
