@@ -241,10 +241,15 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 
   // ---- this workgroup's tile list
   int t_first, t_stride, n_my, xcd = 0;
-  if (grouped) {  // gridDim.x == #CU: XCD group x owns panels x, x+8, ...
+  // CONV: the taps of a dilated convolution read the rows of the neighbouring panels (shift up to +-2 * dilation), so an
+  // XCD owns a CONTIGUOUS run of panels and its CUs walk neighbouring panels at the same time -- the shifted rows are
+  // then found in that XCD's L2 instead of being fetched from HBM once per tap (5x the operand bytes, PMC)
+  const int ppx = (ntm + 7) >> 3;   // panels per XCD in the contiguous deal
+  if (grouped) {  // gridDim.x == #CU: XCD group x owns panels x, x+8, ...  (CONV: panels x*ppx ... x*ppx + ppx - 1)
     xcd = blockIdx.x & 7;
     const int loc = blockIdx.x >> 3, gx = gridDim.x >> 3;
-    const int panels = (ntm - xcd + 7) >> 3;
+    int panels = (ntm - xcd + 7) >> 3;
+    if constexpr (CONV) { panels = ntm - xcd * ppx; panels = panels < 0 ? 0 : (panels > ppx ? ppx : panels); }
     const int tiles_x = panels * ntn;
     t_first = loc; t_stride = gx;
     n_my = tiles_x > loc ? (tiles_x - loc + gx - 1) / gx : 0;
@@ -265,7 +270,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 #endif
   auto tile_origin = [&](int i, int& m0, int& n0) {
     const int j = t_first + i * t_stride;
-    if (grouped) { m0 = ((j / ntn) * 8 + xcd) * BM; n0 = (j % ntn) * BN; }
+    if (grouped) { m0 = (CONV ? xcd * ppx + j / ntn : (j / ntn) * 8 + xcd) * BM; n0 = (j % ntn) * BN; }
     else { m0 = (j / ntn) * BM; n0 = (j % ntn) * BN; }
   };
 

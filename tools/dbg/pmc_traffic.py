@@ -9,6 +9,10 @@ names = {'gemm_p_kernel<1, false, CfgBig, true>': 'gemm_bf16_kernel<EPI_QKV_ROPE
          'gemm_p_kernel<2, false, CfgBig, false>': 'gemm_bf16_kernel<EPI_GATE_RES>',
          'gemm_p_kernel<3, false, CfgBig, false>': 'gemm_bf16_kernel<EPI_BIAS_GELU>',
          'gemm_p_kernel<9, false, CfgRow, false>': 'gemm_bf16_kernel<EPI_GATE_RES_LN>',
+         'gemm_p_kernel<8, false, CfgRow, false>': 'bytenet: gemm_bf16_kernel<EPI_LN_GELU> (1x1, K = 1024)',
+         'gemm_p_kernel<8, true, CfgRow, false>': 'bytenet: gemm_bf16_kernel<EPI_LN_GELU> (dilated conv, K = 2560)',
+         'gemm_p_kernel<6, false, CfgBig, false>': 'bytenet: gemm_bf16_kernel<EPI_RES>',
+         'ln_gelu_kernel<1024>': 'bytenet: ln_gelu_kernel<1024>',
          'attention_kernel': 'attention_kernel', 'attention_kernel<4>': 'attention_kernel', 'ln_mod_kernel<512>': 'ln_mod_kernel'}
 out = {'_note': 'HBM bytes per launch from rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE in separate runs) over '
                 'tools/dbg/dit_fwd.py at B=4096 (the bench shapes). FETCH_SIZE is in KiB and is doubled (gfx950 counts '
