@@ -155,6 +155,27 @@ def test_dit_forward_fused_residual_layernorm_is_bit_identical(rt, monkeypatch, 
     assert torch.equal(small, fused[1070:1073])
 
 
+def test_dit_forward_rows_do_not_depend_on_the_batch_size(rt):
+    """Every GEMM path the launcher can pick -- the 64- and 128-row kernel, the persistent kernel with 256x128 and with
+    256x256 tiles (chosen by round count), the full-row kernel with the fused LayerNorm (from 512 tiles at >= 75 % fill) --
+    must give a sequence the same logits, bit for bit, whatever batch it sits in.  Batch sizes on both sides of each
+    switch (M = B x 119): 8 | 9 (1024 rows), 17 | 18 and 34 | 35 (a quarter of the CUs' worth of tiles for N = 1536 / 512),
+    100, 400 (256x128 wins on rounds), 540 | 560 (511 | 521 full-row tiles), 820."""
+    from sgpo_amd import weights as W
+    sd = W.dit_synthetic_state(seed=22)
+    net = rt.DitDenoiser(sd)
+    g = torch.Generator().manual_seed(12)
+    Lq, Bmax = 119, 820
+    x = torch.randint(0, 31, (Bmax, Lq), generator=g).cuda()
+    sigma = (torch.rand(Bmax, generator=g) * 3).cuda()
+    first = net.forward(x[:1].contiguous(), sigma[:1].contiguous())
+    for B in (8, 9, 17, 18, 34, 35, 64, 100, 137, 200, 400, 540, 560, 820):
+        out = net.forward(x[:B].contiguous(), sigma[:B].contiguous())
+        last = net.forward(x[B - 1:B].contiguous(), sigma[B - 1:B].contiguous())
+        assert torch.equal(out[:1], first), B
+        assert torch.equal(out[B - 1:B], last), B
+
+
 @pytest.mark.parametrize('B', [12, 36])     # M = 1428: 256x128 tiles only; M = 4284: 256x256 tiles with a ragged last tile
 def test_dit_forward_large_batch_uses_persistent_gemm(rt, B):
     """M = B*L >= 1024 routes every GEMM (all epilogues: RoPE, GELU, gate+residual, vocab head) through
