@@ -135,6 +135,23 @@ def test_bytenet_forward_large_batch_matches_small_batch(rt):
         assert torch.equal(hsmall, hbig[sl]) and torch.equal(small, big[sl])
 
 
+def test_bytenet_rows_do_not_depend_on_the_batch_size(rt):
+    """Below the size where the fused LayerNorm GEMM takes over (42 sequences of 389), every GEMM path (64- and 128-row
+    kernel, persistent 256x128 / 256x256 by round count, 1x1 and dilated-conv forms) gives a sequence the same logits
+    whatever batch it is in."""
+    from sgpo_amd import weights as W
+    sd = W.bytenet_synthetic_state(seed=5, n_layers=9)
+    net = rt.BytenetDenoiser(sd)
+    g = torch.Generator().manual_seed(8)
+    x = torch.randint(0, S, (40, 389), generator=g).cuda()
+    tt = torch.randint(1, 500, (40,), generator=g).cuda()
+    first = net.forward(x[:1].contiguous(), tt[:1].contiguous())
+    for B in (2, 3, 5, 6, 11, 21, 22, 40):
+        out = net.forward(x[:B].contiguous(), tt[:B].contiguous())
+        last = net.forward(x[B - 1:B].contiguous(), tt[B - 1:B].contiguous())
+        assert torch.equal(out[:1], first) and torch.equal(out[B - 1:B], last), B
+
+
 def test_bytenet_fused_layernorm_gemm_vs_two_pass_and_oracle(rt, monkeypatch):
     """M = 44 x 389 = 17116 rows (ragged last 128-row tile): the PFF1 and dilated-conv GEMMs take the full-row persistent
     kernel whose epilogue does bias + LayerNorm + GELU (gemm_p.hip EPI_LN_GELU).  Checked against the CPU restatement to
