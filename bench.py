@@ -414,7 +414,11 @@ def main_other(a):
     for i in range(a.warmup):
         one_step(-1 - i)
     sync()
-    if not a.no_prof:
+    # Small batches (configs 1 and 5: kernels of 5-30 us) are launch-bound, and two event records per kernel cost 40-60 % of
+    # the wall clock there (config 5: 100 ms per draw without, 162 ms with them).  Their K steps are timed WITHOUT the
+    # per-kernel events; the kernel table and the roofline come from a second pass over the same K steps right after.
+    prof_in_timed_region = a.config not in (1, 5)
+    if not a.no_prof and prof_in_timed_region:
         L.check(lib.sgpo_prof_enable(1, wl.n_launches(a.steps)), 'prof_enable')
     t0 = time.perf_counter()
     for i in range(a.steps):
@@ -423,6 +427,14 @@ def main_other(a):
     dt = time.perf_counter() - t0
     if world > 1:
         dt = _max_over_ranks(dist, backend, dt, device)
+    dt_prof = dt
+    if not a.no_prof and not prof_in_timed_region:
+        L.check(lib.sgpo_prof_enable(1, wl.n_launches(a.steps)), 'prof_enable')
+        t1 = time.perf_counter()
+        for i in range(a.steps):
+            one_step(i)
+        sync()
+        dt_prof = time.perf_counter() - t1
     roof, kernels = None, {}
     if not a.no_prof:
         n = L.PROF_KINDS
@@ -452,7 +464,11 @@ def main_other(a):
         gt = sum(ms[k] for k in range(n) if lib.sgpo_prof_kind_name(k).decode().startswith(('gemm', 'attention')))
         if gt > 0:
             roof['denoiser_tflops'] = round(gf / (gt * 1e-3) / 1e12, 2)
-        roof['gpu_busy_frac'] = round(tot * 1e-3 / dt, 4)
+        roof['gpu_busy_frac'] = round(tot * 1e-3 / dt_prof, 4)
+        if not prof_in_timed_region:
+            roof['note'] = ('kernel durations from a second pass over the same %d steps with per-kernel events on (%.1f ms per step '
+                            'there): at this batch size the event records themselves are 40-60 %% of the wall clock, so the timed '
+                            'region runs without them' % (a.steps, 1e3 * dt_prof / a.steps))
     if rank == 0:
         cpu = wl.cpu_baseline() if (not a.no_cpu_baseline and world == 1) else None
         cfg = wl.describe()
