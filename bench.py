@@ -282,22 +282,34 @@ class _Config5(_Config4):
         x = self.algo.inference(num_samples=self.B)
         return x, clf.log_likelihood(x)
 
+    DRAWS = 10      # Thompson draws stacked per GPU and bench step (one denoiser forward per reverse step for all of them)
+
+    def _draw_many(self, members, keys):
+        xs = self.algo.inference_many([self.members[m] for m in members], keys, num_samples=self.B)
+        return [(x, self.members[m].log_likelihood(x)) for m, x in zip(members, xs)]
+
     def step(self, i):
         from sgpo_amd.dist import thompson_round
         got = []
-        thompson_round(self._draw, lambda t, s: (got.append((t, s)) or t.shape[0]), n_needed=10 ** 9, max_draws=self.world,
-                       pick_member=lambda: int(self.rng.randint(0, 10)), seed=1000 + i, rank=self.rank, world=self.world)
-        return got[0]
+        thompson_round(self._draw, lambda t, s: (got.append((t, s)) or t.shape[0]), n_needed=10 ** 9,
+                       max_draws=self.world * self.DRAWS, pick_member=lambda: int(self.rng.randint(0, 10)), seed=1000 + i,
+                       rank=self.rank, world=self.world, per_rank=self.DRAWS, draw_many=self._draw_many)
+        return torch.cat([t for t, _ in got]), torch.cat([s for _, s in got])
 
     def units(self):
-        return self.world * self.B
+        return self.world * self.B * self.DRAWS
+
+    def n_launches(self, steps):
+        return steps * (T_STEPS - 1) * (80 + 4 * self.DRAWS) + 64
 
     def describe(self):
         return {'workload': 'MDLM + cls_guidance_discrete (temperature 0.064) on CreiLOV, L=119, 127 reverse steps, Thompson draws of '
-                            '%d sequences, each guided by one of 10 value-function members; one draw per GPU and bench step '
-                            '(ensemble training is outside the timed region: tools/bench_bo.py times a whole round)' % self.B,
+                            '%d sequences, each guided by one of 10 value-function members; %d draws per GPU and bench step, stacked '
+                            '(one denoiser forward per reverse step for all of them, guidance + reverse step per draw; tokens '
+                            'identical to one draw at a time; ensemble training is outside the timed region: tools/bench_bo.py '
+                            'times a whole round)' % (self.B, self.DRAWS),
                 'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate', 'global_batch': self.world * self.B,
-                'parallelism': f'{self.world} draws at a time (independent sampler calls + one all-gather of tokens/scores)'}
+                'parallelism': f'{self.world} x {self.DRAWS} draws at a time (independent sampler calls + one all-gather of tokens/scores)'}
 
     def cpu_baseline(self):
         return cpu_baseline(self.sd, self.msd, n_seq=10, n_steps=24)

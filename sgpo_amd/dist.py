@@ -188,35 +188,46 @@ def share_members(local, n_members, rank=None, world=None, group=None):
     return out
 
 
-def thompson_round(draw, consume, n_needed, max_draws, pick_member, seed, rank=None, world=None, group=None):
+def thompson_round(draw, consume, n_needed, max_draws, pick_member, seed, rank=None, world=None, group=None,
+                   per_rank=1, draw_many=None):
     """One acquisition round of Thompson sampling over an ensemble (iterativeBO.py:204-237) on `world` ranks.
 
     The reference loops: pick a member (numpy RNG), sample a small batch guided by it, hand the batch to update_data,
     stop when the round has its new sequences or after max_iterations draws.  Draws are independent given
-    (member, key), so they are computed a wave of `world` at a time -- rank r computes draw wave * world + r -- and
-    all-gathered once per wave; every rank then CONSUMES the wave in draw order and stops at the same draw the
-    one-rank loop would have stopped at (draws of the wave beyond that point are dropped unseen).
+    (member, key), so they are computed a wave of `world * per_rank` at a time -- rank r computes draws
+    wave[r * per_rank : (r + 1) * per_rank] -- and all-gathered once per wave; every rank then CONSUMES the wave in
+    draw order and stops at the same draw the one-rank loop would have stopped at (draws of the wave beyond that point
+    are dropped unseen).
       pick_member() -> member index; called once per draw, in draw order, on EVERY rank (same numpy seed on all
                        ranks, as util/seed.py sets it, keeps the streams in step);
       draw(member, key) -> (tokens (b, L), scores (b,) or None), this rank's sampler call;
+      draw_many(members, keys) -> list of such pairs: per_rank draws stacked into ONE sampler call
+                       (`Classifier_Guidance_Inpaint.inference_many`: one denoiser forward per step for all of them);
       consume(tokens uint8, scores) -> number of new sequences accepted (update_data on every rank, or on rank 0
                        with the count broadcast by the caller).
     Returns (n_new, n_draws_consumed)."""
     rank, world = _world(rank, world, group)
     n_new = k = 0
     while n_new < n_needed and k < max_draws:
-        # a full wave is always computed, also when fewer than `world` draws remain before max_draws: the surplus is
-        # dropped below (pick_member is thereby called up to world - 1 times more than in the one-rank loop; the
-        # reference reseeds numpy at the start of every round, iterativeBO.py:202, so rounds stay reproducible)
-        wave = list(range(k, k + world))
+        # a full wave is always computed, also when fewer draws remain before max_draws: the surplus is dropped below
+        # (pick_member is thereby called up to wave - 1 times more than in the one-rank loop; the reference reseeds numpy
+        # at the start of every round, iterativeBO.py:202, so rounds stay reproducible)
+        wave = list(range(k, k + world * per_rank))
         members = [pick_member() for _ in wave]
-        d, m = wave[rank], members[rank]
-        x, sc = draw(m, item_seed(seed, d))
-        if world == 1:
-            got = {d: (x.to(torch.uint8), sc)}
+        mine = range(rank * per_rank, (rank + 1) * per_rank)
+        keys = [item_seed(seed, wave[j]) for j in mine]
+        if draw_many is not None:
+            outs = draw_many([members[j] for j in mine], keys)
         else:
-            tag = torch.full((x.shape[0],), d, dtype=torch.int64, device=x.device)
-            got = gather_tagged(x, sc, tag, group=group)
+            outs = [draw(members[j], key) for j, key in zip(mine, keys)]
+        if world == 1:
+            got = {wave[j]: (x.to(torch.uint8), sc) for j, (x, sc) in zip(mine, outs)}
+        else:
+            toks = torch.cat([x for x, _ in outs])
+            have = outs[0][1] is not None
+            scs = torch.cat([sc.to(torch.float32) for _, sc in outs]) if have else None
+            tag = torch.cat([torch.full((x.shape[0],), wave[j], dtype=torch.int64, device=x.device) for j, (x, _) in zip(mine, outs)])
+            got = gather_tagged(toks, scs, tag, group=group)
         for d in wave:
             if n_new >= n_needed or d >= max_draws:
                 break

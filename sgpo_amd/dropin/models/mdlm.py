@@ -268,6 +268,26 @@ class MDLM(GenerativeModel):
             self.check_nan()
         return (xo, p) if want_probs else xo
 
+    @torch.no_grad()
+    def guided_step_groups(self, x, t, groups, guide_temp):
+        """One guided step for SEVERAL independent sampler calls stacked in one batch (Thompson draws of an ensemble,
+        iterativeBO.py:204-237): ONE denoiser forward over all rows, then per group its own value function's jump ratios
+        and its own reverse step with its own Philox stream.  groups: [(predictor_model, NoiseSource, lo, hi)], rows
+        [lo, hi) of x.  A row's logits do not depend on the batch it is in (tests: batch-size invariance), so every group
+        gets exactly the tokens its own `guided_step` call would have produced."""
+        mt, ms, sig_t = self._move_chances(t)
+        logits = self._denoise(x, sig_t)
+        x_out = torch.empty_like(x)
+        for pred, src, lo, hi in groups:
+            xs = x[lo:hi]
+            lr = slots = None
+            if pred is not None and guide_temp != 0:
+                lr, slots = self._jump_log_ratios(pred, xs, t, skip_zero_rate=True)
+            rt.reverse_step_mdlm(logits[lo:hi], xs, mt, ms, self.model.mask_index, L.STEP_SOFT_CG, noise_src=src,
+                                 log_ratio=lr, slot_of_pos=slots, guide_temp=guide_temp, nan_flag=self._nan_flag,
+                                 x_out=x_out[lo:hi])
+        return x_out
+
     def check_nan(self):
         """The reference's two failure modes of a guided step, read back from the kernel's flag: NaN rates
         (`raise ValueError`, models/mdlm.py:410-411) and a row torch.multinomial would refuse (cls_guidance.py:52)."""

@@ -53,6 +53,30 @@ class Classifier_Guidance_Inpaint(Algo):
             return x, detokenized
         return x
 
+    @torch.no_grad()
+    def inference_many(self, forward_ops, seeds, num_samples=1, inpaint=False):
+        """`inference(num_samples)` for several value functions at once -- not in the reference, whose Thompson loop
+        (iterativeBO.py:204-237) calls `update_model(member); inference(10)` once per draw: ten sequences are 1190 rows, a
+        twentieth of what fills the GPU.  The draws are independent, so they are stacked: one denoiser forward per step
+        for all of them, guidance and reverse step per draw with the draw's own Philox key `seeds[i]`.  Returns the list
+        of token batches, each bit-identical to `net.reseed(seeds[i]); update_model(forward_ops[i]); inference(num_samples)`."""
+        from sgpo_amd import runtime as rt
+        n = len(forward_ops)
+        assert n == len(seeds) and n > 0 and hasattr(self.net, 'guided_step_groups')
+        timesteps = torch.linspace(self.net.timestep - 1, 1, int((self.net.timestep - 1) / 1), dtype=int)
+        groups = [(op.eval() if op is not None else None, rt.NoiseSource(seed=sd, row_offset=0), i * num_samples, (i + 1) * num_samples)
+                  for i, (op, sd) in enumerate(zip(forward_ops, seeds))]
+        x = self.net.get_start(n * num_samples)
+        for i, t in enumerate(timesteps):
+            x = self.net.guided_step_groups(x, t, groups, self.temperature)
+            if (i + 1) % self.NAN_CHECK_EVERY == 0:
+                self.net.check_nan()
+            if inpaint:
+                x = self.project(x)
+        self.net.check_nan()
+        x = self.project(x)
+        return [x[lo:hi] for _, _, lo, hi in groups]
+
     def _generic_step(self, x, t):
         """sampling/cls_guidance.py:34-52 for nets without a fused step."""
         from sgpo_amd import runtime as rt

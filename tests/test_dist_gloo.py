@@ -122,13 +122,14 @@ class _Store:
         return new
 
 
-def _thompson(world, rank, n_needed, max_draws):
+def _thompson(world, rank, n_needed, max_draws, per_rank=1):
     import numpy as np
     from sgpo_amd.dist import thompson_round
     rng = np.random.RandomState(11)                      # util/seed.py: every rank seeds numpy alike
     store = _Store(n_needed)
+    many = (lambda members, keys: [_stub_draw(m, k) for m, k in zip(members, keys)]) if per_rank > 1 else None
     n_new, k = thompson_round(_stub_draw, store.consume, n_needed, max_draws, lambda: int(rng.randint(0, 10)), seed=3,
-                              rank=rank, world=world)
+                              rank=rank, world=world, per_rank=per_rank, draw_many=many)
     return n_new, k, store.rows, store.scores
 
 
@@ -148,6 +149,8 @@ def _worker_cells(rank, world, port, q):
         # Thompson round: same accepted rows, same stopping draw as the one-rank loop
         for n_needed, max_draws in ((20, 50), (1000, 7), (3, 50)):
             ok = ok and _thompson(world, rank, n_needed, max_draws) == _thompson(1, 0, n_needed, max_draws)
+            # several draws stacked per rank and wave (draw_many): still the one-rank, one-draw-at-a-time result
+            ok = ok and _thompson(world, rank, n_needed, max_draws, per_rank=3) == _thompson(1, 0, n_needed, max_draws)
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -211,3 +211,54 @@ def test_config5_ensemble_member_guides_batches_of_10(env):
             xs = xs.clone()
             xs[:, ::3] = 28
     tf.finish('config5_member')
+
+
+def test_config5_stacked_thompson_draws_equal_one_draw_at_a_time(env):
+    """`inference_many`: several Thompson draws (different ensemble members, different Philox keys) stacked into one
+    batch -- one denoiser forward per step for all of them -- give every draw exactly the tokens of its own
+    `update_model(member); net.reseed(key); inference(10)` call, and `thompson_round(per_rank=...)` consumes them to the
+    same result as the one-draw-at-a-time loop (iterativeBO.py:204-237)."""
+    import bench
+    from problem.protein import ProteinPredictor
+    from sgpo_amd import dist as D
+    from sgpo_amd import weights as W
+    net, pred0, algo, sd, msd = bench.build('cuda:0', 10)
+    net.timestep = 24                                   # a short horizon keeps the test quick; the loop is the same
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=119, full_seq=CREILOV, residues=None)
+    members = []
+    for m in range(4):
+        p = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+        p.model.load_state_dict(W.mlp_synthetic_state(seed=200 + m, n_residues=119))
+        members.append(p.eval())
+    picks, keys = [2, 0, 3, 3, 1], [D.item_seed(9, d) for d in range(5)]
+    stacked = algo.inference_many([members[m] for m in picks], keys, num_samples=10)
+    for m, key, got in zip(picks, keys, stacked):
+        algo.update_model(members[m])
+        net.reseed(seed=key, row_offset=0)
+        assert torch.equal(got, algo.inference(num_samples=10))
+    assert not torch.equal(stacked[2], stacked[3])       # same member, different key
+
+    def run(per_rank):
+        rng = np.random.RandomState(5)
+        seen = []
+
+        def draw(m, key):
+            algo.update_model(members[m])
+            net.reseed(seed=key, row_offset=0)
+            x = algo.inference(num_samples=10)
+            return x, members[m].log_likelihood(x)
+
+        def draw_many(ms, ks):
+            xs = algo.inference_many([members[m] for m in ms], ks, num_samples=10)
+            return [(x, members[m].log_likelihood(x)) for m, x in zip(ms, xs)]
+
+        def consume(t, s):
+            seen.append((t.cpu(), s.cpu()))
+            return 4
+        out = D.thompson_round(draw, consume, n_needed=14, max_draws=20, pick_member=lambda: int(rng.randint(0, 4)), seed=21,
+                               rank=0, world=1, per_rank=per_rank, draw_many=draw_many if per_rank > 1 else None)
+        return out, seen
+    (a, seen_a), (b, seen_b) = run(1), run(3)
+    assert a == b == (16, 4) and len(seen_a) == len(seen_b) == 4
+    for (ta, sa), (tb, sb) in zip(seen_a, seen_b):
+        assert torch.equal(ta, tb) and torch.equal(sa, sb)
