@@ -31,6 +31,7 @@ def main():
     ap.add_argument('--per-round', type=int, default=100)
     ap.add_argument('--draw', type=int, default=10)
     ap.add_argument('--temperature', type=float, default=0.064)
+    ap.add_argument('--stack', type=int, default=10, help='Thompson draws stacked per sampler call (1 = one draw at a time)')
     a = ap.parse_args()
 
     import sgpo_amd
@@ -92,7 +93,32 @@ def main():
             n_new = it = 0
             max_it = max(5 * a.per_round // a.draw, 5)
             t_inf = t_upd = 0.0
-            while n_new < a.per_round and it < max_it:
+            if a.stack > 1:
+                # the wave form of the same loop (sgpo_amd.dist.thompson_round): `stack` draws in one sampler call, consumed
+                # in draw order, so the round ends at the draw the loop below would end at
+                from sgpo_amd.dist import thompson_round
+                algo = Classifier_Guidance_Inpaint(net, dc, forward_op=clfs[0], temperature=a.temperature, device=dev)
+                clock = dict(inf=0.0, upd=0.0)
+
+                def draw_many(ms, keys):
+                    t1 = time.perf_counter()
+                    xs = algo.inference_many([clfs[m] for m in ms], keys, num_samples=a.draw)
+                    torch.cuda.synchronize()
+                    clock['inf'] += time.perf_counter() - t1
+                    return [(x, None) for x in xs]
+
+                def consume(t, _s):
+                    t1 = time.perf_counter()
+                    got = ds.update_data(algo.project_tokens(t.to(torch.int64)), a.per_round - consume.n, BO=True, round=1)
+                    torch.cuda.synchronize()
+                    clock['upd'] += time.perf_counter() - t1
+                    consume.n += got
+                    return got
+                consume.n = 0
+                n_new, it = thompson_round(None, consume, a.per_round, max_it, lambda: int(np.random.randint(0, a.members)), seed=7,
+                                           rank=0, world=1, per_rank=a.stack, draw_many=draw_many)
+                t_inf, t_upd = clock['inf'], clock['upd']
+            while a.stack <= 1 and n_new < a.per_round and it < max_it:
                 clf = clfs[np.random.randint(0, a.members)]
                 algo = Classifier_Guidance_Inpaint(net, dc, forward_op=clf, temperature=a.temperature, device=dev)
                 algo.update_model(clf)
