@@ -228,6 +228,11 @@ int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_read, const
 void sgpo_mlp_trainer_destroy(sgpo_mlp_trainer* t);
 int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L,
                           double lr, double beta1, double beta2, double eps, float* loss_out, void* stream);
+/* n_steps consecutive optimiser steps in one call: batch j of every member at x + j*[n_members][B][L] (likewise t, y),
+ * its losses at loss_out + j*[n_members].  Same kernels and bits as n_steps calls of sgpo_mlp_trainer_step (the batches of
+ * an epoch of train_classifier.py:26-41 are known up front); saves the caller's per-step overhead (0.32 -> 0.25 ms). */
+int sgpo_mlp_trainer_steps(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int n_steps, int B, int L,
+                           double lr, double beta1, double beta2, double eps, float* loss_out, void* stream);
 int sgpo_mlp_trainer_read(const sgpo_mlp_trainer* t, float* blobs_out, void* stream);
 
 /* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb

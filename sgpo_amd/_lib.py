@@ -63,6 +63,7 @@ SIGNATURES = {
     'sgpo_mlp_trainer_create': (_i, [_vp, _i, _i, C.POINTER(_i), _i, _i, _i, C.POINTER(_vp)]),
     'sgpo_mlp_trainer_destroy': (None, [_vp]),
     'sgpo_mlp_trainer_step': (_i, [_vp, _vp, _vp, _vp, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp]),
+    'sgpo_mlp_trainer_steps': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, C.c_double, C.c_double, C.c_double, C.c_double, _vp, _vp]),
     'sgpo_mlp_trainer_read': (_i, [_vp, _vp, _vp]),
     'sgpo_nos_workspace_bytes': (_sz, [_vp, _i, _i]),
     'sgpo_nos_denoise': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _i, _f, _f, _f, _f, _i, _i, _i, _vp, _u64, _u64, _u64,

@@ -492,13 +492,8 @@ extern "C" int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_
   return SGPO_OK;
 }
 
-extern "C" int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L,
-                                     double lr, double beta1, double beta2, double eps, float* loss_out, void* stream) {
-  SGPO_REQUIRE(t && x && y && loss_out, "mlp_trainer_step: null argument");
-  SGPO_REQUIRE(B > 0 && B <= TB, "mlp_trainer_step: batch %d outside 1..%d", B, TB);
-  SGPO_REQUIRE(!t->d.time_cond || tt, "mlp_trainer_step: a time-conditioned model needs t");
-  SGPO_REQUIRE(t->max_read_pos < L, "mlp_trainer_step: value function reads position %d of a length-%d row", t->max_read_pos, L);
-  hipStream_t s = (hipStream_t)stream;
+static int trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L, double lr,
+                        double beta1, double beta2, double eps, float* loss_out, hipStream_t s) {
   const TrDev& d = t->d;
   hipLaunchKernelGGL(tr_fwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);
   hipLaunchKernelGGL(tr_reduce, dim3((d.E * TB * H + 255) / 256), dim3(256), 0, s, d, B);
@@ -512,6 +507,27 @@ extern "C" int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, cons
                      (float)beta1, (float)beta2, (float)eps);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
+}
+
+extern "C" int sgpo_mlp_trainer_steps(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int n_steps, int B,
+                                      int L, double lr, double beta1, double beta2, double eps, float* loss_out, void* stream) {
+  SGPO_REQUIRE(t && x && y && loss_out, "mlp_trainer_step: null argument");
+  SGPO_REQUIRE(n_steps > 0, "mlp_trainer_steps: n_steps=%d", n_steps);
+  SGPO_REQUIRE(B > 0 && B <= TB, "mlp_trainer_step: batch %d outside 1..%d", B, TB);
+  SGPO_REQUIRE(!t->d.time_cond || tt, "mlp_trainer_step: a time-conditioned model needs t");
+  SGPO_REQUIRE(t->max_read_pos < L, "mlp_trainer_step: value function reads position %d of a length-%d row", t->max_read_pos, L);
+  const size_t E = t->d.E;
+  for (int j = 0; j < n_steps; ++j) {
+    const int rc = trainer_step(t, x + (size_t)j * E * B * L, tt ? tt + (size_t)j * E * B : nullptr, y + (size_t)j * E * B, B, L, lr,
+                                beta1, beta2, eps, loss_out + (size_t)j * E, (hipStream_t)stream);
+    if (rc) return rc;
+  }
+  return SGPO_OK;
+}
+
+extern "C" int sgpo_mlp_trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L,
+                                     double lr, double beta1, double beta2, double eps, float* loss_out, void* stream) {
+  return sgpo_mlp_trainer_steps(t, x, tt, y, 1, B, L, lr, beta1, beta2, eps, loss_out, stream);
 }
 
 extern "C" int sgpo_mlp_trainer_read(const sgpo_mlp_trainer* t, float* blobs_out, void* stream) {

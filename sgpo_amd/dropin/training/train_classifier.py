@@ -74,8 +74,7 @@ def train_classifier_ensemble(classifiers, model, dataloader, train_config, save
                 xb = xt[:, :nb * bs].reshape(E, nb, bs, Lq).transpose(0, 1).contiguous()
                 tb = tf[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
                 yb = y[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
-                for j in range(nb):
-                    trainer.step(xb[j], tb[j], yb[j], lr=lr)
+                trainer.steps(xb, tb, yb, lr=lr)                  # the nb full batches, one library call
             if G > nb * bs:                                           # the ragged last batch (drop_last=False)
                 trainer.step(xt[:, nb * bs:].contiguous(), tf[:, nb * bs:].contiguous(), y[:, nb * bs:].contiguous(), lr=lr)
     for c, sd in zip(classifiers, trainer.state_dicts()):

@@ -251,6 +251,24 @@ class MlpEnsembleTrainer:
                                                float(betas[1]), float(eps), L.ptr(loss), L.stream_ptr()), 'sgpo_mlp_trainer_step')
         return loss
 
+    def steps(self, x, t, y, lr=1e-3, betas=(0.9, 0.999), eps=1e-8):
+        """n consecutive optimiser steps in one library call: x (n, E, B, L) int64, t (n, E, B) or None, y (n, E, B);
+        returns the losses (n, E).  Same kernels and bits as n calls of `step`."""
+        n, E, B, Lq = x.shape
+        assert E == self.n_members and tuple(y.shape) == (n, E, B)
+        if max(self.read_pos) >= Lq:
+            raise L.SgpoError(f'value function reads position {max(self.read_pos)} of a length-{Lq} sequence')
+        x = x.to(self.device, torch.int64).contiguous()
+        y = y.to(self.device, torch.float32).contiguous()
+        tt = None
+        if self.time_conditioned:
+            tt = t.to(self.device, torch.float32).contiguous()
+            assert tuple(tt.shape) == (n, E, B)
+        loss = torch.empty(n, E, dtype=torch.float32, device=self.device)
+        L.check(self.lib.sgpo_mlp_trainer_steps(self.handle, L.ptr(x), L.ptr(tt), L.ptr(y), n, B, Lq, float(lr), float(betas[0]),
+                                                float(betas[1]), float(eps), L.ptr(loss), L.stream_ptr()), 'sgpo_mlp_trainer_steps')
+        return loss
+
     def state_dicts(self):
         blob = torch.empty(self.n_members, self.n_params, dtype=torch.float32, device=self.device)
         L.check(self.lib.sgpo_mlp_trainer_read(self.handle, L.ptr(blob), L.stream_ptr()), 'sgpo_mlp_trainer_read')

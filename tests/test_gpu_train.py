@@ -77,6 +77,22 @@ def test_trainer_members_with_their_own_batches(rt):
     torch.testing.assert_close(vf.forward(x.cuda(), torch.full((9,), 5.0)).cpu(), ref, rtol=1e-4, atol=1e-5)
 
 
+def test_trainer_several_steps_in_one_call(rt):
+    """`sgpo_mlp_trainer_steps`: n batches in one library call give the weights and losses of n single-step calls, bit for bit."""
+    from sgpo_amd import weights as W
+    gen = torch.Generator().manual_seed(9)
+    Lq, E, n, B = 119, 3, 7, 64
+    states = [W.mlp_synthetic_state(seed=60 + e, n_residues=Lq) for e in range(E)]
+    x = torch.randint(0, 31, (n, E, B, Lq), generator=gen).cuda()
+    t = torch.randint(0, 128, (n, E, B), generator=gen).float().cuda()
+    y = torch.randn(n, E, B, generator=gen).cuda()
+    one, many = rt.MlpEnsembleTrainer(states, list(range(Lq))), rt.MlpEnsembleTrainer(states, list(range(Lq)))
+    losses = torch.stack([one.step(x[j], t[j], y[j]) for j in range(n)])
+    assert torch.equal(many.steps(x, t, y), losses)
+    for a, b in zip(one.state_dicts(), many.state_dicts()):
+        assert all(torch.equal(a[k], b[k]) for k in a)
+
+
 def test_trainer_rejects_bad_shapes(rt):
     from sgpo_amd import weights as W
     sd = W.mlp_synthetic_state(seed=1, n_residues=10)
