@@ -63,3 +63,20 @@ def test_two_ranks_dealt_cells_equal_one_rank(parts, tmp_path):
         x = algo.inference(num_samples=n)
         assert torch.equal(got['tokens'][i].long(), x.cpu()), i
         assert torch.equal(got['scores'][i], pred.log_likelihood(x).detach().float().cpu()), i
+
+
+def test_two_ranks_stacked_thompson_draws_equal_the_one_rank_loop(tmp_path):
+    """Config 5 across ranks with the real sampler: waves of 2 ranks x 2 stacked draws, consumed in draw order, stop at the
+    same draw with the same tokens and scores as one rank drawing one at a time."""
+    sys.path.insert(0, HERE)
+    import bench
+    import dist_gpu_worker as worker
+    from sgpo_amd import dist as D
+    got = _launch('thompson', str(tmp_path / 'thompson.pt'))
+    want = worker.thompson_job(D, bench, 0, 1, per_rank=1)
+    assert got['result'] == want['result'] == [18, 6]
+    assert len(got['tokens']) == len(want['tokens']) == 6
+    for a, b in zip(got['tokens'], want['tokens']):
+        assert torch.equal(a, b)
+    for a, b in zip(got['scores'], want['scores']):
+        assert torch.equal(a, b)
