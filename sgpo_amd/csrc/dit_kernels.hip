@@ -209,6 +209,7 @@ int launch_ln_mod(const float* x, const float* w, const float* shift, const floa
 //                                      converted to bf16 in place (k order of the accumulator).
 // qkv: [M][3*Hd] bf16 (q | k | v sections, heads contiguous inside a section), RoPE already applied.
 #define ATT_D 64
+typedef uint32_t u32x4_att __attribute__((ext_vector_type(4)));
 #ifndef ATT_ABL
 #define ATT_ABL 0   // diagnostic builds only (tools/dbg/att_bench.hip): 1 no stores, 2 no key loop, 4 no K/V loads
 #endif
@@ -312,27 +313,38 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : NW == 8 ? 2 : 1) void attent
           if (key >= L) s[r] = -1e30f;
         }
       }
-      float tmax = s[0];
+      float tmax = fmaxf(s[0], s[1]);
 #pragma unroll
-      for (int r = 1; r < 16; ++r) tmax = fmaxf(tmax, s[r]);
-      tmax = fmaxf(tmax, __shfl_xor(tmax, 32)) * scale_log2e;   // scale > 0: max commutes with it
+      for (int r = 2; r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(s[r], s[r + 1]), tmax);   // v_max3_f32
+      {   // the other 16 keys of the tile are in lane ^ 32: one v_permlane32_swap (VALU) instead of a trip through the LDS crossbar
+        const auto hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+        tmax = fmaxf(__uint_as_float(hx[0]), __uint_as_float(hx[1])) * scale_log2e;   // scale > 0: max commutes with it
+      }
       const float m_new = fmaxf(m_run, tmax);
       const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
       float psum = 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_new)); psum += s[r]; }
-      psum += __shfl_xor(psum, 32);
+      {
+        const auto hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+        psum = __uint_as_float(hx[0]) + __uint_as_float(hx[1]);
+      }
       l_run = l_run * alpha + psum;
       m_run = m_new;
+      // the running maximum settles after the first key tiles; when it moved in no lane, alpha is exactly 1 everywhere and
+      // the 32 multiplies are skipped (same bits).  At L = 389 the loop is VALU-bound: 16 v_exp_f32 + these per 8 MFMAs.
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
+      }
       // P^T as the B operand of the next product: k-step st uses registers 8st..8st+7; element j of
       // lane-half lh is key 16st + 8(j>>2) + 4 lh + (j&3) of this tile.
 #pragma unroll
       for (int st = 0; st < 2; ++st) {
-        bf16x8 pf;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) pf[j] = (__bf16)s[st * 8 + j];
+        u32x4_att pw;   // one v_cvt_pk_bf16_f32 per pair
+        pw.x = pack_bf16x2(s[st * 8 + 0], s[st * 8 + 1]); pw.y = pack_bf16x2(s[st * 8 + 2], s[st * 8 + 3]);
+        pw.z = pack_bf16x2(s[st * 8 + 4], s[st * 8 + 5]); pw.w = pack_bf16x2(s[st * 8 + 6], s[st * 8 + 7]);
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         // A operand: V^T[d = lr (+32)][keys kt*32 + st*16 + 4 lh + {0..3, 8..11}] by transposed reads of V
         const char* vb = v_lds + (kt * 32 + st * 16) * 128;
         typedef short s16x4_t __attribute__((ext_vector_type(4)));
