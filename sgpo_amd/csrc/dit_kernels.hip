@@ -1,6 +1,7 @@
 // Non-GEMM kernels of the MDLM denoiser (DiT): conditioning MLP + adaLN tables,
 // embedding gather, LayerNorm+modulate, short-sequence attention.
 // Reference: models/pretraining/model/mdlm/models/dit.py (line refs per kernel).
+#include <stdlib.h>
 #include "common.h"
 #include "ln_stats.h"
 #include "dit.h"
@@ -214,6 +215,125 @@ typedef uint32_t u32x4_att __attribute__((ext_vector_type(4)));
 #define ATT_ABL 0   // diagnostic builds only (tools/dbg/att_bench.hip): 1 no stores, 2 no key loop, 4 no K/V loads
 #endif
 
+// One (32-query tile) x (32-key tile) step of the online softmax, shared by both attention kernels so that they give the
+// same bits: S^T = K Q^T, running max / sum per query (lane-local + one exchange with lane ^ 32), O^T += V^T P^T.
+// k_tile / v_tile: the tile's K rows (chunk c of row r at c ^ ((r >> 1) & 7)) and V rows (c ^ ((r & 3) << 1)) in LDS.
+struct AttState { f32x16 o0, o1; float m_run, l_run; };
+__device__ __forceinline__ void att_tile(const char* k_tile, const char* v_tile, const bf16x8 (&qf)[4], AttState& a, int kt, int L,
+                                         float scale_log2e, int lr, int lh, int v_off0, int v_off1) {
+  f32x16 s;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) s[r] = 0.f;
+  const char* kr = k_tile + lr * 128;
+  const int sw = (lr >> 1) & 7;
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (((kk * 2 + lh) ^ sw) << 4));
+    s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
+  }
+  // s[r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*lh][query = lr]  (unscaled)
+  if (kt * 32 + 32 > L) {   // only the last key tile can hold padding keys (wave-uniform)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      if (key >= L) s[r] = -1e30f;
+    }
+  }
+  float tmax = fmaxf(s[0], s[1]);
+#pragma unroll
+  for (int r = 2; r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(s[r], s[r + 1]), tmax);   // v_max3_f32
+  {   // the other 16 keys of the tile are in lane ^ 32: one v_permlane32_swap (VALU) instead of a trip through the LDS crossbar
+    const auto hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
+    tmax = fmaxf(__uint_as_float(hx[0]), __uint_as_float(hx[1])) * scale_log2e;   // scale > 0: max commutes with it
+  }
+  const float m_new = fmaxf(a.m_run, tmax);
+  const float alpha = __builtin_amdgcn_exp2f(a.m_run - m_new);
+  float psum = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_new)); psum += s[r]; }
+  {
+    const auto hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
+    psum = __uint_as_float(hx[0]) + __uint_as_float(hx[1]);
+  }
+  a.l_run = a.l_run * alpha + psum;
+  a.m_run = m_new;
+  // the running maximum settles after the first key tiles; when it moved in no lane, alpha is exactly 1 everywhere and
+  // the 32 multiplies are skipped (same bits).  At L = 389 the loop is VALU-bound: 16 v_exp_f32 + these per 8 MFMAs.
+  if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a.o0[r] *= alpha; a.o1[r] *= alpha; }
+  }
+  // P^T as the B operand of the next product: k-step st uses registers 8st..8st+7; element j of
+  // lane-half lh is key 16st + 8(j>>2) + 4 lh + (j&3) of this tile.
+#pragma unroll
+  for (int st = 0; st < 2; ++st) {
+    u32x4_att pw;   // one v_cvt_pk_bf16_f32 per pair
+    pw.x = pack_bf16x2(s[st * 8 + 0], s[st * 8 + 1]); pw.y = pack_bf16x2(s[st * 8 + 2], s[st * 8 + 3]);
+    pw.z = pack_bf16x2(s[st * 8 + 4], s[st * 8 + 5]); pw.w = pack_bf16x2(s[st * 8 + 6], s[st * 8 + 7]);
+    const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+    // A operand: V^T[d = lr (+32)][keys kt*32 + st*16 + 4 lh + {0..3, 8..11}] by transposed reads of V
+    const char* vb = v_tile + (st * 16) * 128;
+    typedef short s16x4_t __attribute__((ext_vector_type(4)));
+    typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
+    const s16x4_t va = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off0));
+    const s16x4_t vc = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off0 + 8 * 128));
+    const s16x4_t vd = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off1));
+    const s16x4_t ve = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off1 + 8 * 128));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    const s16x8_t v0s = __builtin_shufflevector(va, vc, 0, 1, 2, 3, 4, 5, 6, 7);
+    const s16x8_t v1s = __builtin_shufflevector(vd, ve, 0, 1, 2, 3, 4, 5, 6, 7);
+    const bf16x8 v0 = __builtin_bit_cast(bf16x8, v0s), v1 = __builtin_bit_cast(bf16x8, v1s);
+    a.o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, a.o0, 0, 0, 0);
+    a.o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, a.o1, 0, 0, 0);
+  }
+}
+
+// ---- O[query][d] = O^T / l ; lane owns query q, rows d = (r&3)+8(r>>2)+4lh (+32), i.e. the 8-byte
+// halves of 16-byte chunk g (and 4+g) of its output row, the other half being in lane^32.  Stored like that,
+// a wave's 16 store instructions visit 512 cache lines and the CU's address unit (about one line per cycle)
+// costs the kernel a third of its time.  One v_permlane32_swap per register instead hands lane half 0 the
+// even chunks and half 1 the odd ones, whole: 4 instructions of 16 bytes per lane.
+__device__ __forceinline__ void att_store(const AttState& a, bf16_t* orow_base, bool valid, int lh) {
+  const float inv = 1.0f / a.l_run;
+  uint32_t w0[8], w1[8];   // w[2g], w[2g+1]: this lane's half of chunk g
+#pragma unroll
+  for (int g = 0; g < 4; ++g) {
+    w0[2 * g] = pack_bf16x2(a.o0[g * 4 + 0] * inv, a.o0[g * 4 + 1] * inv);
+    w0[2 * g + 1] = pack_bf16x2(a.o0[g * 4 + 2] * inv, a.o0[g * 4 + 3] * inv);
+    w1[2 * g] = pack_bf16x2(a.o1[g * 4 + 0] * inv, a.o1[g * 4 + 1] * inv);
+    w1[2 * g + 1] = pack_bf16x2(a.o1[g * 4 + 2] * inv, a.o1[g * 4 + 3] * inv);
+  }
+  // swap(X = half of chunk 2k, Y = half of chunk 2k+1): lanes 32..63 of X <-> lanes 0..31 of Y.  Afterwards the
+  // lower lanes hold chunk 2k as (X, Y) and the upper lanes chunk 2k+1 as (X, Y).
+#pragma unroll
+  for (int k = 0; k < 2; ++k)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      auto r0 = __builtin_amdgcn_permlane32_swap(w0[4 * k + j], w0[4 * k + 2 + j], false, false);
+      w0[4 * k + j] = r0[0]; w0[4 * k + 2 + j] = r0[1];
+      auto r1 = __builtin_amdgcn_permlane32_swap(w1[4 * k + j], w1[4 * k + 2 + j], false, false);
+      w1[4 * k + j] = r1[0]; w1[4 * k + 2 + j] = r1[1];
+    }
+  if (valid && (!(ATT_ABL & 1) || a.l_run == 12345.f)) {
+    bf16_t* orow = orow_base + lh * 8;
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+      *reinterpret_cast<uint4*>(orow + 16 * k) = make_uint4(w0[4 * k], w0[4 * k + 1], w0[4 * k + 2], w0[4 * k + 3]);
+      *reinterpret_cast<uint4*>(orow + 32 + 16 * k) = make_uint4(w1[4 * k], w1[4 * k + 1], w1[4 * k + 2], w1[4 * k + 3]);
+    }
+  }
+}
+
+__device__ __forceinline__ void att_block_to_bh(int n_heads, int& b, int& h) {
+  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  The heads of one sequence read
+  // neighbouring 128-B pieces of the same qkv rows, so they are given ids 8 apart: same XCD (one L2),
+  // dispatched back to back.  Sequences beyond the last multiple of 8 use the plain order.
+  const int per = 8 * n_heads, grp = blockIdx.x / per, r = blockIdx.x - grp * per;
+  const int n_seq = gridDim.x / n_heads;
+  if ((grp + 1) * 8 <= n_seq) { b = grp * 8 + (r & 7); h = r >> 3; }
+  else { b = blockIdx.x / n_heads; h = blockIdx.x % n_heads; }
+}
+
 // NW waves per workgroup: 4 for short sequences (5 workgroups per CU), 8 once the K/V images leave room for two
 // workgroups per CU (L > 160: twice the waves in flight behind the same LDS bytes), 16 when only one fits (L > 320)
 template <int NW>
@@ -222,16 +342,8 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : NW == 8 ? 2 : 1) void attent
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int hid = n_heads * ATT_D;
   const int ld = 3 * hid;
-  // Workgroups are dealt to the 8 XCDs round-robin (blockIdx % 8).  The heads of one sequence read
-  // neighbouring 128-B pieces of the same qkv rows, so they are given ids 8 apart: same XCD (one L2),
-  // dispatched back to back.  Sequences beyond the last multiple of 8 use the plain order.
   int b, h;
-  {
-    const int per = 8 * n_heads, grp = blockIdx.x / per, r = blockIdx.x - grp * per;
-    const int n_seq = gridDim.x / n_heads;
-    if ((grp + 1) * 8 <= n_seq) { b = grp * 8 + (r & 7); h = r >> 3; }
-    else { b = blockIdx.x / n_heads; h = blockIdx.x % n_heads; }
-  }
+  att_block_to_bh(n_heads, b, h);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int lr = lane & 31, lh = lane >> 5;
   char* k_lds = smem;              // Lp * 128 B, chunk c of row r at c ^ ((r >> 1) & 7)
@@ -287,114 +399,90 @@ __global__ __launch_bounds__(64 * NW, NW == 4 ? 5 : NW == 8 ? 2 : 1) void attent
       for (int kk = 0; kk < 4; ++kk)
         qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
     }
-
-    f32x16 o0, o1;  // O^T tiles: d in [0,32), [32,64); column = query (lane)
+    AttState a;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { o0[r] = 0.f; o1[r] = 0.f; }
-    float m_run = -1e30f, l_run = 0.f;
-
-    for (int kt = 0; kt < ((ATT_ABL & 2) ? 0 : n_tiles); ++kt) {
-      f32x16 s;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) s[r] = 0.f;
-      const int krow = kt * 32 + lr;
-      const char* kr = k_lds + krow * 128;
-      const int sw = (krow >> 1) & 7;
-#pragma unroll
-      for (int kk = 0; kk < 4; ++kk) {
-        bf16x8 kf = *reinterpret_cast<const bf16x8*>(kr + (((kk * 2 + lh) ^ sw) << 4));
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[kk], s, 0, 0, 0);
-      }
-      // s[r] = S^T[key = kt*32 + (r&3) + 8*(r>>2) + 4*lh][query = lr]  (unscaled)
-      if (kt * 32 + 32 > L) {   // only the last key tile can hold padding keys (wave-uniform)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-          if (key >= L) s[r] = -1e30f;
-        }
-      }
-      float tmax = fmaxf(s[0], s[1]);
-#pragma unroll
-      for (int r = 2; r < 16; r += 2) tmax = __builtin_fmaxf(__builtin_fmaxf(s[r], s[r + 1]), tmax);   // v_max3_f32
-      {   // the other 16 keys of the tile are in lane ^ 32: one v_permlane32_swap (VALU) instead of a trip through the LDS crossbar
-        const auto hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(tmax), __float_as_uint(tmax), false, false);
-        tmax = fmaxf(__uint_as_float(hx[0]), __uint_as_float(hx[1])) * scale_log2e;   // scale > 0: max commutes with it
-      }
-      const float m_new = fmaxf(m_run, tmax);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], scale_log2e, -m_new)); psum += s[r]; }
-      {
-        const auto hx = __builtin_amdgcn_permlane32_swap(__float_as_uint(psum), __float_as_uint(psum), false, false);
-        psum = __uint_as_float(hx[0]) + __uint_as_float(hx[1]);
-      }
-      l_run = l_run * alpha + psum;
-      m_run = m_new;
-      // the running maximum settles after the first key tiles; when it moved in no lane, alpha is exactly 1 everywhere and
-      // the 32 multiplies are skipped (same bits).  At L = 389 the loop is VALU-bound: 16 v_exp_f32 + these per 8 MFMAs.
-      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) { o0[r] *= alpha; o1[r] *= alpha; }
-      }
-      // P^T as the B operand of the next product: k-step st uses registers 8st..8st+7; element j of
-      // lane-half lh is key 16st + 8(j>>2) + 4 lh + (j&3) of this tile.
-#pragma unroll
-      for (int st = 0; st < 2; ++st) {
-        u32x4_att pw;   // one v_cvt_pk_bf16_f32 per pair
-        pw.x = pack_bf16x2(s[st * 8 + 0], s[st * 8 + 1]); pw.y = pack_bf16x2(s[st * 8 + 2], s[st * 8 + 3]);
-        pw.z = pack_bf16x2(s[st * 8 + 4], s[st * 8 + 5]); pw.w = pack_bf16x2(s[st * 8 + 6], s[st * 8 + 7]);
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-        // A operand: V^T[d = lr (+32)][keys kt*32 + st*16 + 4 lh + {0..3, 8..11}] by transposed reads of V
-        const char* vb = v_lds + (kt * 32 + st * 16) * 128;
-        typedef short s16x4_t __attribute__((ext_vector_type(4)));
-        typedef __attribute__((address_space(3))) s16x4_t* lds_s16x4_t;
-        const s16x4_t a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off0));
-        const s16x4_t c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off0 + 8 * 128));
-        const s16x4_t d = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off1));
-        const s16x4_t e = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_t)(vb + v_off1 + 8 * 128));
-        typedef short s16x8_t __attribute__((ext_vector_type(8)));
-        const s16x8_t v0s = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
-        const s16x8_t v1s = __builtin_shufflevector(d, e, 0, 1, 2, 3, 4, 5, 6, 7);
-        const bf16x8 v0 = __builtin_bit_cast(bf16x8, v0s), v1 = __builtin_bit_cast(bf16x8, v1s);
-        o0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v0, pf, o0, 0, 0, 0);
-        o1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(v1, pf, o1, 0, 0, 0);
-      }
-    }
-    // ---- O[query][d] = O^T / l ; lane owns query qt*32+lr, rows d = (r&3)+8(r>>2)+4lh (+32), i.e. the 8-byte
-    // halves of 16-byte chunk g (and 4+g) of its output row, the other half being in lane^32.  Stored like that,
-    // a wave's 16 store instructions visit 512 cache lines and the CU's address unit (about one line per cycle)
-    // costs the kernel a third of its time.  One v_permlane32_swap per register instead hands lane half 0 the
-    // even chunks and half 1 the odd ones, whole: 4 instructions of 16 bytes per lane.
-    const float inv = 1.0f / l_run;
-    uint32_t w0[8], w1[8];   // w[2g], w[2g+1]: this lane's half of chunk g
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      w0[2 * g] = pack_bf16x2(o0[g * 4 + 0] * inv, o0[g * 4 + 1] * inv);
-      w0[2 * g + 1] = pack_bf16x2(o0[g * 4 + 2] * inv, o0[g * 4 + 3] * inv);
-      w1[2 * g] = pack_bf16x2(o1[g * 4 + 0] * inv, o1[g * 4 + 1] * inv);
-      w1[2 * g + 1] = pack_bf16x2(o1[g * 4 + 2] * inv, o1[g * 4 + 3] * inv);
-    }
-    // swap(X = half of chunk 2k, Y = half of chunk 2k+1): lanes 32..63 of X <-> lanes 0..31 of Y.  Afterwards the
-    // lower lanes hold chunk 2k as (X, Y) and the upper lanes chunk 2k+1 as (X, Y).
-#pragma unroll
-    for (int k = 0; k < 2; ++k)
-#pragma unroll
-      for (int j = 0; j < 2; ++j) {
-        auto r0 = __builtin_amdgcn_permlane32_swap(w0[4 * k + j], w0[4 * k + 2 + j], false, false);
-        w0[4 * k + j] = r0[0]; w0[4 * k + 2 + j] = r0[1];
-        auto r1 = __builtin_amdgcn_permlane32_swap(w1[4 * k + j], w1[4 * k + 2 + j], false, false);
-        w1[4 * k + j] = r1[0]; w1[4 * k + 2 + j] = r1[1];
-      }
+    for (int r = 0; r < 16; ++r) { a.o0[r] = 0.f; a.o1[r] = 0.f; }
+    a.m_run = -1e30f; a.l_run = 0.f;
+    for (int kt = 0; kt < ((ATT_ABL & 2) ? 0 : n_tiles); ++kt)
+      att_tile(k_lds + kt * 32 * 128, v_lds + kt * 32 * 128, qf, a, kt, L, scale_log2e, lr, lh, v_off0, v_off1);
     const int q = qt * 32 + lr;
-    if (q < L && (!(ATT_ABL & 1) || l_run == 12345.f)) {
-      bf16_t* orow = out + ((size_t)b * L + q) * hid + h * ATT_D + lh * 8;
+    att_store(a, out + ((size_t)b * L + q) * hid + h * ATT_D, q < L, lh);
+  }
+}
+
+// Long sequences (L > 320, where the K/V images of one head leave room for a single workgroup per CU and nothing
+// overlaps its staging with its key loop): K/V tiles of 32 keys stream through a 4-slot LDS ring (LDS-DMA, one 1-KiB
+// piece per wave and stage, counted waits, one barrier per key tile), 32 KiB per workgroup, so two 8-wave workgroups
+// share a CU.  A wave owns query tiles wave, wave + 8; each round of query tiles streams the keys again (from L2).
+// Same tile arithmetic (att_tile) as the resident kernel: same bits.  Rows beyond L are read from row L - 1 (finite
+// values; their probabilities are exactly 0).
+#define ATT_NSTG 4
+template <int NW>
+__global__ __launch_bounds__(64 * NW, NW == 8 ? 2 : 1) void attention_stream_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out, int L,
+                                                                                    int Lp, int n_heads, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // ATT_NSTG x (K tile 4 KiB | V tile 4 KiB)
+  typedef const __attribute__((address_space(1))) void* gptr_t;
+  typedef __attribute__((address_space(3))) void* lptr_t;
+  const int hid = n_heads * ATT_D;
+  const int ld = 3 * hid;
+  int b, h;
+  att_block_to_bh(n_heads, b, h);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 31, lh = lane >> 5;
+  const bf16_t* base = qkv + (size_t)b * L * ld + h * ATT_D;
+  const int tq = (lane >> 2) & 3, tp = lane & 3, dblk = lr >> 4;
+  const int v_off0 = (lh * 4 + tq) * 128 + (((dblk * 2 + (tp >> 1)) ^ (tq << 1)) << 4) + (tp & 1) * 8;
+  const int v_off1 = (lh * 4 + tq) * 128 + (((4 + dblk * 2 + (tp >> 1)) ^ (tq << 1)) << 4) + (tp & 1) * 8;
+  const int n_tiles = Lp / 32;
+  // this wave's piece of every stage: waves 0-3 rows 8w..8w+7 of the K tile, waves 4-7 of the V tile (waves 8+ stage nothing)
+  const bool stager = wave < 8;
+  const bool is_v = wave >= 4;
+  const int prow = (wave & 3) * 8 + (lane >> 3), pc = lane & 7;
+  const int src_c = pc ^ (is_v ? ((prow & 3) << 1) : ((prow >> 1) & 7));   // the swizzle is applied on the source side
+  const bf16_t* src0 = base + (is_v ? 2 * hid : hid) + src_c * 8;
+  const int dst_off = (is_v ? 4096 : 0) + (wave & 3) * 1024;
+  auto stage = [&](int kt) {
+    if (!stager) return;
+    int row = kt * 32 + prow;
+    if (row > L - 1) row = L - 1;
+    __builtin_amdgcn_global_load_lds((gptr_t)(src0 + (size_t)row * ld), (lptr_t)(smem + (kt % ATT_NSTG) * 8192 + dst_off), 16, 0, 0);
+  };
+  for (int q0 = 0; q0 < n_tiles; q0 += NW) {
+    const int qt = q0 + wave;
+    const bool active = qt < n_tiles;    // wave-uniform; idle waves still stage and meet the barriers
+    bf16x8 qf[4];
+    {
+      int qrow = qt * 32 + lr;
+      if (qrow > L - 1) qrow = L - 1;
 #pragma unroll
-      for (int k = 0; k < 2; ++k) {
-        *reinterpret_cast<uint4*>(orow + 16 * k) = make_uint4(w0[4 * k], w0[4 * k + 1], w0[4 * k + 2], w0[4 * k + 3]);
-        *reinterpret_cast<uint4*>(orow + 32 + 16 * k) = make_uint4(w1[4 * k], w1[4 * k + 1], w1[4 * k + 2], w1[4 * k + 3]);
-      }
+      for (int kk = 0; kk < 4; ++kk)
+        qf[kk] = *reinterpret_cast<const bf16x8*>(base + (size_t)qrow * ld + kk * 16 + lh * 8);
     }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // Q fragments (and the stores of the round before) are out of the queue
+#pragma unroll
+    for (int s0 = 0; s0 < ATT_NSTG - 1; ++s0)
+      if (s0 < n_tiles) stage(s0);
+    AttState a;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { a.o0[r] = 0.f; a.o1[r] = 0.f; }
+    a.m_run = -1e30f; a.l_run = 0.f;
+    for (int kt = 0; kt < n_tiles; ++kt) {
+      const int ahead = min(ATT_NSTG - 2, n_tiles - 1 - kt);   // younger stages that may still be in flight
+      if (ahead >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+      else if (ahead == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();   // every wave's piece of tile kt is visible; every read of tile kt - 1 is done
+      asm volatile("" ::: "memory");
+      if (kt + ATT_NSTG - 1 < n_tiles) stage(kt + ATT_NSTG - 1);
+      const char* slot = smem + (kt % ATT_NSTG) * 8192;
+      if (active && !(ATT_ABL & 2)) att_tile(slot, slot + 4096, qf, a, kt, L, scale_log2e, lr, lh, v_off0, v_off1);
+    }
+    if (active) {
+      const int q = qt * 32 + lr;
+      att_store(a, out + ((size_t)b * L + q) * hid + h * ATT_D, q < L, lh);
+    }
+    __syncthreads();   // the next round's first stages reuse the slots the last tiles were read from
   }
 }
 
@@ -415,7 +503,13 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
   ProfScope prof_scope(PK_ATTENTION, stream, 4.0 * B * n_heads * (double)L * L * head_dim);
-  if (lds > 80 * 1024)   // one workgroup per CU: 16 waves cover up to 16 query tiles in one round
+  static int stream_mode = -1;
+  if (stream_mode < 0) { const char* e = getenv("SGPO_ATT_STREAM"); stream_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3 : 1; }   // A/B measurements
+  if (lds > 80 * 1024 && stream_mode == 2)
+    hipLaunchKernelGGL(attention_stream_kernel<16>, dim3(B * n_heads), dim3(1024), ATT_NSTG * 8192, stream, qkv, out, L, Lp, n_heads, scale_log2e);
+  else if ((lds > 80 * 1024 && stream_mode) || (lds > 40 * 1024 && stream_mode == 3))   // the resident images would leave one workgroup per CU: stream the keys instead
+    hipLaunchKernelGGL(attention_stream_kernel<8>, dim3(B * n_heads), dim3(512), ATT_NSTG * 8192, stream, qkv, out, L, Lp, n_heads, scale_log2e);
+  else if (lds > 80 * 1024)   // one workgroup per CU: 16 waves cover up to 16 query tiles in one round
     hipLaunchKernelGGL(attention_kernel<16>, dim3(B * n_heads), dim3(1024), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
   else if (lds > 40 * 1024)
     hipLaunchKernelGGL(attention_kernel<8>, dim3(B * n_heads), dim3(512), lds, stream, qkv, out, L, Lp, n_heads, scale_log2e);
