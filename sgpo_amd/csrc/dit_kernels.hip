@@ -490,9 +490,12 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
   SGPO_REQUIRE(head_dim == ATT_D, "attention: head_dim %d unsupported (64 only)", head_dim);
   const int Lp = (L + 31) / 32 * 32;
   const size_t lds = (size_t)Lp * 256;   // K and V images
-  SGPO_REQUIRE(lds <= 160 * 1024, "attention: sequence length %d exceeds the LDS-resident limit", L);
+  static int stream_mode = -1;
+  if (stream_mode < 0) { const char* e = getenv("SGPO_ATT_STREAM"); stream_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3 : 1; }   // A/B measurements
+  // the streaming kernel has no length limit of its own; only the resident kernels need both images in LDS
+  SGPO_REQUIRE(stream_mode != 0 || lds <= 160 * 1024, "attention: sequence length %d exceeds the LDS-resident limit", L);
   static size_t attr_lds = 0;
-  if (lds > attr_lds) {
+  if (lds > attr_lds && lds <= 160 * 1024) {
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<4>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attention_kernel<8>),
@@ -503,8 +506,6 @@ int launch_attention(const bf16_t* qkv, bf16_t* out, int B, int L, int n_heads, 
   }
   const float scale_log2e = 1.4426950408889634f / sqrtf((float)head_dim);
   ProfScope prof_scope(PK_ATTENTION, stream, 4.0 * B * n_heads * (double)L * L * head_dim);
-  static int stream_mode = -1;
-  if (stream_mode < 0) { const char* e = getenv("SGPO_ATT_STREAM"); stream_mode = (e && e[0] == '0') ? 0 : (e && e[0] == '2') ? 2 : (e && e[0] == '3') ? 3 : 1; }   // A/B measurements
   if (lds > 80 * 1024 && stream_mode == 2)
     hipLaunchKernelGGL(attention_stream_kernel<16>, dim3(B * n_heads), dim3(1024), ATT_NSTG * 8192, stream, qkv, out, L, Lp, n_heads, scale_log2e);
   else if ((lds > 80 * 1024 && stream_mode) || (lds > 40 * 1024 && stream_mode == 3))   // the resident images would leave one workgroup per CU: stream the keys instead

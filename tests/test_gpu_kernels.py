@@ -89,12 +89,16 @@ def test_dit_forward(rt, name):
                                       (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 320),
                                       (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 321),
                                       (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 1, 512),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 2, 700),
+                                      (dict(hidden=128, cond_dim=32, n_blocks=1, n_heads=2), 1, 1024),
                                       (dict(hidden=256, cond_dim=64, n_blocks=2, n_heads=4), 2, 50)])   # a width between the two with goldens
 def test_dit_forward_long_sequences(rt, dims, B, L):
     """TrpB length (389) and the lengths around the attention kernel's variants: a single key tile (20), idle
     waves (33), the first length past the 4-wave kernel (161: K/V images > 40 KB switch to 8 waves per workgroup),
-    the last 8-wave and first 16-wave length (320 / 321), two full rounds of query tiles (512).  Device logits
-    against the CPU restatement rounding to bf16 where autocast does."""
+    the last length with K/V resident in LDS and the first that streams them through the ring (320 / 321), two full
+    rounds of query tiles (512), lengths past what the resident kernels could hold at all (700: 22 tiles, a ragged
+    third round; 1024: the default max_len).  Device logits against the CPU restatement rounding to bf16 where
+    autocast does."""
     from oracle import dit as odit
     from sgpo_amd import weights as W
     sd = W.dit_synthetic_state(seed=9, vocab=31, **dims)
