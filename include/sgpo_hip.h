@@ -238,7 +238,8 @@ int sgpo_mlp_trainer_read(const sgpo_mlp_trainer* t, float* blobs_out, void* str
 /* ---- NOS step: MDLM._nos_denoise (models/mdlm.py:184-338) with the DITClassifier head on x_emb
  * (dit.py:494-515: mean-pool over L + Linear(hidden, 1); w_cls = its weight, [hidden] fp32).
  * One backbone pass, then num_nos_steps closed-form gradient + Adagrad updates of delta
- * (B x L x hidden, in the workspace) on the final layer only, then the guided reverse step
+ * (B x L x hidden; held in registers over all inner steps by ONE kernel launch, written out only
+ * through delta_out) on the final layer only, then the guided reverse step
  * (_sample_categorical + carry-over).  kl_batch: the B of KLDivLoss(reduction='batchmean')
  * (models/mdlm.py:254,297) -- pass the GLOBAL per-call batch when a batch is sharded over ranks.
  * noise: [B][L][vocab] uniforms for noise_mode 2.  probs_out (optional) [B][L][vocab] = guided_probs;
