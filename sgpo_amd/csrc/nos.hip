@@ -128,19 +128,30 @@ __device__ __forceinline__ v2f nos_softmax(v2f zl, bool valid, bool first) {
   return e * v2f{1.0f / sum.x, 1.0f / sum.y};
 }
 
+// grad = dx - w_cls / L: the product is rounded before the subtraction (as `0 - c` needs it for unmasked rows)
+__device__ __forceinline__ v2f nos_grad(v2f dx, float w_cls, float inv_L) {
+#pragma clang fp contract(off)
+  const float c = w_cls * inv_L;
+  return dx - c;
+}
+
 // Adagrad on one element pair: G += grad^2, delta -= lr grad / (sqrt(G) + 1e-10).  v_sqrt_f32 and v_rcp_f32 (1 ulp
 // each) instead of the correctly rounded expansions, which are ~25 instructions per element and made the update as
 // expensive as a sweep over W; the relative error per step (~3e-7) is far inside the test tolerance on delta (2e-3).
+// (No contraction in here: the same operations wherever it is inlined, so an unmasked row gets the same bits from the
+// per-column closed form as from riding along in a pair with a masked row.)
 __device__ __forceinline__ void nos_adagrad(v2f& G, v2f& delta, v2f grad, float lr) {
-  G = G + grad * grad;
+#pragma clang fp contract(off)
+  G = __builtin_elementwise_fma(grad, grad, G);
   const v2f den = v2f{__builtin_amdgcn_sqrtf(G.x), __builtin_amdgcn_sqrtf(G.y)} + 1e-10f;
-  delta = delta - (lr * grad) * v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  const v2f step = (lr * grad) * v2f{__builtin_amdgcn_rcpf(den.x), __builtin_amdgcn_rcpf(den.y)};
+  delta = delta - step;
 }
 
 // The whole NOS optimisation of a row in ONE launch: rows are independent across inner steps, so delta and the
 // Adagrad accumulator G stay in registers from the first step to the last and never touch HBM (the per-step version
-// moved 20 H bytes per row and step and was bound by that).  The waves of a workgroup share W in LDS; a wave draws row pairs from a
-// counter (a pair with masked rows costs ~12 sweeps of W, one without costs 1, so a fixed deal leaves waves idle).
+// moved 20 H bytes per row and step and was bound by that).  The waves of a workgroup share W in LDS; a wave draws
+// row pairs from counters (a pair with masked rows costs ~12 sweeps of W, one without 1: a fixed deal leaves waves idle).
 //   p0 = softmax(logits(h));  n_steps x { z(h + delta) -> dz -> closed-form backward -> Adagrad };  logits(h + delta)
 // Unmasked rows: dL/dz is 0 there, so the gradient is the constant -w_cls / L and delta follows a recurrence that
 // is the same for every such row (dU, once per wave; same bits as the full computation: dx = rstd * (0 - 0 - y * 0)
@@ -169,7 +180,7 @@ __global__ __launch_bounds__(NOS_THREADS) void nos_fused_kernel(NosArgs a) {
     for (int i = 0; i < PER; ++i) { Gu[i] = v2(0.f); du[i] = v2(0.f); }
     for (int s = 0; s < a.n_steps; ++s)
 #pragma unroll
-      for (int i = 0; i < PER; ++i) nos_adagrad(Gu[i], du[i], v2(0.f) - a.w_cls[i * 64 + lane] * a.inv_L, a.lr);
+      for (int i = 0; i < PER; ++i) nos_adagrad(Gu[i], du[i], nos_grad(v2(0.f), a.w_cls[i * 64 + lane], a.inv_L), a.lr);
 #pragma unroll
     for (int i = 0; i < PER; ++i) dU[i] = du[i].x;
   }
@@ -257,7 +268,7 @@ __global__ __launch_bounds__(NOS_THREADS) void nos_fused_kernel(NosArgs a) {
       }
       // grad = dx - w_cls / L (the mean-pool + Linear head), then Adagrad
 #pragma unroll
-      for (int i = 0; i < PER; ++i) nos_adagrad(G[i], delta[i], dx[i] - a.w_cls[i * 64 + lane] * a.inv_L, a.lr);   // (w_cls from L1: 8 registers fewer)
+      for (int i = 0; i < PER; ++i) nos_adagrad(G[i], delta[i], nos_grad(dx[i], a.w_cls[i * 64 + lane], a.inv_L), a.lr);   // (w_cls from L1: 8 registers fewer)
     }
     // the final logits are formed for every row
     v2f zl;

@@ -122,6 +122,14 @@ def test_nos_hidden_256_against_oracle(env):
     ok = ((top2[..., 0] - top2[..., 1]) > 1e-2 * top2[..., 0]) | (x != 28)
     assert ok.float().mean() > 0.9 and torch.equal(xs.cpu()[ok], xs_ref[ok])
     assert torch.equal(xs.cpu()[2], x[2])
+    # no inner steps: delta stays 0 and the call is the plain guided reverse step from the unshifted hidden state
+    _, p0_ref, _ = onos.nos_denoise(sd, w_cls, b_cls, x, t, T, 28, 0, lr, coef, u)
+    _, p0, d0 = rt.nos_denoise(net.net, x.cuda(), w_cls, 0, lr, coef, mt, ms, 28, want_delta=True, noise=u, hidden_in=hs[-1])
+    assert float(d0.abs().max()) == 0.0
+    torch.testing.assert_close(p0.cpu(), p0_ref, rtol=1e-4, atol=1e-6)
+    # every inner step of an unmasked row has the same gradient -w_cls / L: its delta is a function of the column
+    # only (the kernel forms it once per wave), so the rows of sequence 2 and the unmasked rows of the others agree
+    assert torch.equal(d[2, 0], d[2, -1]) and torch.equal(d[0, 1], d[2, 0])
 
 
 def test_nos_sampler_loop(env):
