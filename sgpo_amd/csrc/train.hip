@@ -33,6 +33,37 @@ struct TrDev {
   int o_tw, o_t1w, o_t1b, o_ew, o_eb, o_w0, o_b0, o_w1, o_b1, o_w2, o_b2, o_c0, o_c0b, o_c2, o_c2b;
 };
 
+
+// ---- 64 x 64 x 64 products on the matrix cores, fp32 (v_mfma_f32_32x32x2_f32) ----
+// A workgroup of 4 waves forms C = A B; wave w owns the 32 x 32 quadrant (w >> 1, w & 1).  a_at(m, k) and b_at(k, n)
+// read LDS (one element each per k pair: 64 reads per lane and product, against 1088 for the FMA form that bounded
+// these kernels); `init` is the accumulator's starting value (the bias of the lane's column).  The summation order
+// is the MFMA's, fixed: a run stays reproducible bit for bit.
+struct Quad {
+  int row0, col;   // acc[r] is element (row0 + (r >> 2) * 8 + (r & 3), col)
+};
+__device__ __forceinline__ Quad quad_of_lane() {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  return Quad{(w >> 1) * 32 + (lane >> 5) * 4, (w & 1) * 32 + (lane & 31)};
+}
+template <class FA, class FB>
+__device__ __forceinline__ f32x16 mfma64(FA a_at, FB b_at, float init) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m = (w >> 1) * 32 + (lane & 31), n = (w & 1) * 32 + (lane & 31), kh = lane >> 5;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = init;
+#pragma unroll 8
+  for (int k = 0; k < H; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_at(m, k + kh), b_at(k + kh, n), acc, 0, 0, 0);
+  return acc;
+}
+template <class F>
+__device__ __forceinline__ void quad_store(const f32x16& acc, F put) {   // put(row, col, value)
+  const Quad q = quad_of_lane();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) put(q.row0 + (r >> 2) * 8 + (r & 3), q.col, acc[r]);
+}
+
 // in[b][k] of chunk c: embedding of the token at read position c, or the time embedding (c == n_read)
 template <int P1>
 __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const int64_t* x, const float* t, int B, int L,
@@ -76,56 +107,26 @@ __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const 
     const float* bb = p + d.o_t1b;
     for (int idx = tid; idx < H * H; idx += 256) in[idx >> 6][idx & 63] = w[idx];
     __syncthreads();
-    float acc[TB * H / 256];
-#pragma unroll
-    for (int it = 0; it < TB * H / 256; ++it) {
-      const int idx = tid + it * 256, b = idx >> 6, j = idx & 63;
-      float a = 0.f;
-      if (b < B) {
-        a = bb[j];
-        for (int k = 0; k < H; ++k) a = fmaf(in[j][k], tmp[b][k], a);
-      }
-      acc[it] = a;
-    }
+    // out[b][j] = bias[j] + sum_k f[b][k] W[j][k]
+    const f32x16 acc = mfma64([&](int m, int k) { return tmp[m][k]; }, [&](int k, int n) { return in[n][k]; }, bb[quad_of_lane().col]);
     __syncthreads();
-#pragma unroll
-    for (int it = 0; it < TB * H / 256; ++it) {
-      const int idx = tid + it * 256;
-      in[idx >> 6][idx & 63] = acc[it];
-    }
+    quad_store(acc, [&](int b, int j, float v) { in[b][j] = b < B ? v : 0.f; });
   }
 }
 
-constexpr int PADV = H + 4;    // rows that are read four columns at a time (16-byte aligned)
-
 __global__ __launch_bounds__(256) void tr_fwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
-  __shared__ __attribute__((aligned(16))) float in[TB][PADV], wt[H][PADV];   // wt[k][o]: the weight chunk transposed
+  __shared__ float in[TB][PAD], ws[H][PAD];
   const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
-  chunk_input(d, p, e, c, x, t, B, L, in, wt, true);
+  chunk_input(d, p, e, c, x, t, B, L, in, ws, true);
   __syncthreads();
   const float* w0 = p + d.o_w0 + (size_t)c * H;
-  for (int idx = tid; idx < H * H; idx += 256) wt[idx & 63][idx >> 6] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
+  for (int idx = tid; idx < H * H; idx += 256) ws[idx >> 6][idx & 63] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
   __syncthreads();
-  const int o = tid & 63, bg = tid >> 6;
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  // the batch rows are broadcast reads, four k at a time; per accumulator the k order is unchanged
-  for (int k = 0; k < H; k += 4) {
-    const float wa = wt[k][o], wb = wt[k + 1][o], wc = wt[k + 2][o], wd = wt[k + 3][o];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) {
-      const float4 v = *reinterpret_cast<const float4*>(&in[bg * 16 + j][k]);
-      acc[j] = fmaf(v.x, wa, acc[j]);
-      acc[j] = fmaf(v.y, wb, acc[j]);
-      acc[j] = fmaf(v.z, wc, acc[j]);
-      acc[j] = fmaf(v.w, wd, acc[j]);
-    }
-  }
+  // partial pre-activation: out[b][o] = sum_k in[b][k] W0[o][c * 64 + k]
+  const f32x16 acc = mfma64([&](int m, int k) { return in[m][k]; }, [&](int k, int n) { return ws[n][k]; }, 0.f);
   float* out = d.part_h + (((size_t)e * d.C + c) * TB) * H;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) out[(bg * 16 + j) * H + o] = acc[j];
+  quad_store(acc, [&](int b, int o, float v) { out[b * H + o] = v; });
 }
 
 // ordered sum of the chunk partials + bias -> pre-activation of mlp.0 (written over chunk 0's slot)
@@ -153,64 +154,34 @@ __device__ void load_w(float (*wb)[PAD], const float* w) {
   for (int idx = threadIdx.x; idx < H * H; idx += 256) wb[idx >> 6][idx & 63] = w[idx];
   __syncthreads();
 }
-// out[b][o] = act(bias[o] + sum_k in[b][k] W[o][k]);  pre (optional) keeps the sign information for the backward pass
+// out[b][o] = act(bias[o] + sum_k in[b][k] W[o][k])
 __device__ void lin_fwd(float (*out)[PAD], float (*in)[PAD], float (*wb)[PAD], const float* bias, bool relu, int B) {
-  const int o = threadIdx.x & 63, bg = threadIdx.x >> 6;
-  float acc[16];
-  const float bo = bias[o];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = bo;
-  for (int k = 0; k < H; ++k) {
-    const float w = wb[o][k];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[bg * 16 + j][k], w, acc[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int b = bg * 16 + j;
-    float v = acc[j];
+  const f32x16 acc = mfma64([&](int m, int k) { return in[m][k]; }, [&](int k, int n) { return wb[n][k]; }, bias[quad_of_lane().col]);
+  quad_store(acc, [&](int b, int o, float v) {
     if (relu) v = v > 0.f ? v : 0.f;
     out[b][o] = b < B ? v : 0.f;
-  }
+  });
   __syncthreads();
 }
-// dW[o][k] = sum_b dz[b][o] a[b][k];  db[o] = sum_b dz[b][o]
+// dW[o][k] = sum_b dz[b][o] a[b][k];  db[o] = sum_b dz[b][o]   (rows >= B of dz are zero)
 __device__ void grad_w(float* dW, float* db, float (*dz)[PAD], float (*a)[PAD], int B) {
-  const int k = threadIdx.x & 63, og = threadIdx.x >> 6;
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  for (int b = 0; b < B; ++b) {
-    const float av = a[b][k];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = fmaf(dz[b][og * 16 + j], av, acc[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) dW[(og * 16 + j) * H + k] = acc[j];
+  const f32x16 acc = mfma64([&](int m, int k) { return dz[k][m]; }, [&](int k, int n) { return a[k][n]; }, 0.f);
+  quad_store(acc, [&](int o, int k, float v) { dW[o * H + k] = v; });
   if (threadIdx.x < H) {
     float s = 0.f;
     for (int b = 0; b < B; ++b) s += dz[b][threadIdx.x];
     db[threadIdx.x] = s;
   }
 }
-// da[b][k] = (sum_o dz[b][o] W[o][k]) * (mask ? act[b][k] > 0 : 1)
+// da[b][k] = (sum_o dz[b][o] W[o][k]) * (mask ? act[b][k] > 0 : 1);  da may be dz or act (the products are in
+// registers before the barrier that precedes the stores)
 __device__ void grad_in(float (*da)[PAD], float (*dz)[PAD], float (*wb)[PAD], float (*act)[PAD], bool relu_mask, int B) {
-  const int k = threadIdx.x & 63, bg = threadIdx.x >> 6;
-  float acc[16];
-#pragma unroll
-  for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-  for (int o = 0; o < H; ++o) {
-    const float w = wb[o][k];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = fmaf(dz[bg * 16 + j][o], w, acc[j]);
-  }
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int b = bg * 16 + j;
-    float v = acc[j];
+  const f32x16 acc = mfma64([&](int m, int k) { return dz[m][k]; }, [&](int k, int n) { return wb[k][n]; }, 0.f);
+  __syncthreads();
+  quad_store(acc, [&](int b, int k, float v) {
     if (relu_mask && !(act[b][k] > 0.f)) v = 0.f;
     da[b][k] = b < B ? v : 0.f;
-  }
+  });
   __syncthreads();
 }
 
@@ -315,20 +286,11 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
     toks[tid] = tok;
   }
   __syncthreads();
-  // d mlp.0.weight[o][c*64 + k] = sum_b dh[b][o] in[b][k]
+  // d mlp.0.weight[o][c*64 + k] = sum_b dh[b][o] in[b][k]   (rows >= B of both are zero)
   {
-    const int k = tid & 63, og = tid >> 6;
-    float acc[16];
-#pragma unroll
-    for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-    for (int b = 0; b < B; ++b) {
-      const float av = in[b][k];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = fmaf(dh[b][og * 16 + j], av, acc[j]);
-    }
+    const f32x16 acc = mfma64([&](int m, int k) { return dh[k][m]; }, [&](int k, int n) { return in[k][n]; }, 0.f);
     float* gw = g + d.o_w0 + (size_t)c * H;
-#pragma unroll
-    for (int j = 0; j < 16; ++j) gw[(size_t)(og * 16 + j) * d.D + k] = acc[j];
+    quad_store(acc, [&](int o, int k, float v) { gw[(size_t)o * d.D + k] = v; });
   }
   if (c < d.n_read) {
     __syncthreads();
@@ -357,20 +319,14 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
     __syncthreads();
     grad_in(in, dh, ws, in, false, B);   // in := d temb  (grad_in reads dh/ws only, then overwrites `in`)
     // d t1.weight[j][k] = sum_b dtemb[b][j] f[b][k]: the Fourier features come back from where tr_fwd0 stored them
+    // (through ws, free now, with zero rows past the batch: the buffer holds nothing defined there)
     {
       const float* f = d.fbuf + (size_t)e * TB * H;
-      const int k = tid & 63, og = tid >> 6;
-      float acc[16];
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[j] = 0.f;
-      for (int b = 0; b < B; ++b) {
-        const float av = f[b * H + k];
-#pragma unroll
-        for (int j = 0; j < 16; ++j) acc[j] = fmaf(in[b][og * 16 + j], av, acc[j]);
-      }
+      for (int idx = tid; idx < TB * H; idx += 256) ws[idx >> 6][idx & 63] = (idx >> 6) < B ? f[idx] : 0.f;
+      __syncthreads();
+      const f32x16 acc = mfma64([&](int m, int k) { return in[k][m]; }, [&](int k, int n) { return ws[k][n]; }, 0.f);
       float* dW = g + d.o_t1w;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) dW[(og * 16 + j) * H + k] = acc[j];
+      quad_store(acc, [&](int j, int k, float v) { dW[j * H + k] = v; });
       if (tid < H) {
         float sb = 0.f;
         for (int b = 0; b < B; ++b) sb += in[b][tid];
