@@ -118,10 +118,16 @@ __global__ __launch_bounds__(256) void tr_fwd0(TrDev d, const int64_t* __restric
   __shared__ float in[TB][PAD], ws[H][PAD];
   const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
+  // the weight slice is requested before the input chunk is gathered (token -> embedding is two dependent loads):
+  // one memory latency for both instead of one after the other
+  const float* w0 = p + d.o_w0 + (size_t)c * H;
+  float wreg[H * H / 256];
+#pragma unroll
+  for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; wreg[it] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)]; }
   chunk_input(d, p, e, c, x, t, B, L, in, ws, true);
   __syncthreads();
-  const float* w0 = p + d.o_w0 + (size_t)c * H;
-  for (int idx = tid; idx < H * H; idx += 256) ws[idx >> 6][idx & 63] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
+#pragma unroll
+  for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; ws[idx >> 6][idx & 63] = wreg[it]; }
   __syncthreads();
   // partial pre-activation: out[b][o] = sum_k in[b][k] W0[o][c * 64 + k]
   const f32x16 acc = mfma64([&](int m, int k) { return in[m][k]; }, [&](int k, int n) { return ws[n][k]; }, 0.f);
@@ -269,14 +275,19 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
   const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
   float* g = d.grads + (size_t)e * d.P;
-  chunk_input(d, p, e, c, x, t, B, L, in, ws, false);   // for the time chunk ws holds the Fourier features meanwhile
-  __syncthreads();
   const float* w0 = p + d.o_w0 + (size_t)c * H;
   const float* dhg = d.dh + (size_t)e * TB * H;
-  for (int idx = tid; idx < H * H; idx += 256) {
-    ws[idx >> 6][idx & 63] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
+  float wreg[H * H / 256];   // requested before the gather of the input chunk, like tr_fwd0
+#pragma unroll
+  for (int it = 0; it < H * H / 256; ++it) {
+    const int idx = tid + it * 256;
+    wreg[it] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)];
     dh[idx >> 6][idx & 63] = dhg[idx];
   }
+  chunk_input(d, p, e, c, x, t, B, L, in, ws, false);   // for the time chunk ws holds the Fourier features meanwhile
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; ws[idx >> 6][idx & 63] = wreg[it]; }
   if (tid < TB && c < d.n_read) {
     int tok = 0;
     if (tid < B) {
@@ -336,41 +347,73 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
   }
 }
 
-__global__ void tr_adam(TrDev d, float lr_over_bc1, float bc2_sqrt, float beta1, float beta2, float eps) {
-  const size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
-  if (i >= (size_t)d.E * d.P) return;
-  const int e = (int)(i / d.P), q = (int)(i % d.P);
-  if (q < d.o_t1w) return;   // GaussianFourierProjection.W: requires_grad=False
-  float gr;
-  if (q >= d.o_ew && q < d.o_b0 && q < d.o_w0) {
-    // embedder: ordered sum of the per-position partials
-    const float* pe = d.part_e + (size_t)e * d.n_read * 32 * H;
-    int row, k;
-    if (q < d.o_eb) { k = (q - d.o_ew) / d.A; row = (q - d.o_ew) % d.A; }
-    else { k = q - d.o_eb; row = 31; }
-    gr = 0.f;
-    // loads eight positions ahead of the (ordered) adds: the chain is otherwise one memory latency per term
-    int c = 0;
-    for (; c + 8 <= d.n_read; c += 8) {
-      float v8[8];
+// gradient of parameter q of member e: the embedder's is the ordered sum of the per-position partials
+__device__ __forceinline__ float adam_grad(const TrDev& d, int e, int q, float stored) {
+  if (!(q >= d.o_ew && q < d.o_b0 && q < d.o_w0)) return stored;   // (callers only pass embedder parameters)
+  const float* pe = d.part_e + (size_t)e * d.n_read * 32 * H;
+  int row, k;
+  if (q < d.o_eb) { k = (q - d.o_ew) / d.A; row = (q - d.o_ew) % d.A; }
+  else { k = q - d.o_eb; row = 31; }
+  float gr = 0.f;
+  // loads eight positions ahead of the (ordered) adds: the chain is otherwise one memory latency per term
+  int c = 0;
+  for (; c + 8 <= d.n_read; c += 8) {
+    float v8[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v8[u] = pe[((size_t)(c + u) * 32 + row) * H + k];
+    for (int u = 0; u < 8; ++u) v8[u] = pe[((size_t)(c + u) * 32 + row) * H + k];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) gr += v8[u];
-    }
-    for (; c < d.n_read; ++c) gr += pe[((size_t)c * 32 + row) * H + k];
-  } else {
-    gr = d.grads[i];
+    for (int u = 0; u < 8; ++u) gr += v8[u];
   }
-  // torch.optim.Adam (single-tensor path): exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
-  // value=1 - beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-step_size)
-  float m = d.m[i], v = d.v[i];
+  for (; c < d.n_read; ++c) gr += pe[((size_t)c * 32 + row) * H + k];
+  return gr;
+}
+// torch.optim.Adam (single-tensor path): exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
+// value=1 - beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-step_size)
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gr, float lr_over_bc1, float bc2_sqrt,
+                                            float beta1, float beta2, float eps) {
   m = m + (gr - m) * (1.0f - beta1);
   v = v * beta2 + (1.0f - beta2) * gr * gr;
-  d.m[i] = m;
-  d.v[i] = v;
   const float denom = sqrtf(v) / bc2_sqrt + eps;
-  d.params[i] = d.params[i] - lr_over_bc1 * (m / denom);
+  p = p - lr_over_bc1 * (m / denom);
+}
+// Four consecutive parameters of the flat [E][P] arrays per thread (16-byte loads and stores: the pass moves 28 bytes
+// per parameter and is bound by that); a quad may straddle two members.  The embedder's parameters, whose gradient is
+// a 119-term ordered sum, are left to the first `emb_blocks` blocks (dispatched first: they take longest), one thread
+// each (four of those chains in one thread made the whole pass wait for them).
+__global__ __launch_bounds__(256) void tr_adam(TrDev d, int emb_blocks, float lr_over_bc1, float bc2_sqrt, float beta1, float beta2, float eps) {
+  const int emb_lo = d.o_ew, emb_hi = d.o_b0 < d.o_w0 ? d.o_b0 : d.o_w0;
+  if ((int)blockIdx.x < emb_blocks) {
+    const int n_emb = emb_hi - emb_lo;
+    const int j = (int)blockIdx.x * 256 + threadIdx.x;
+    if (j >= d.E * n_emb) return;
+    const int e = j / n_emb, q = emb_lo + j % n_emb;
+    const size_t i = (size_t)e * d.P + q;
+    adam_update(d.params[i], d.m[i], d.v[i], adam_grad(d, e, q, 0.f), lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+    return;
+  }
+  const size_t n = (size_t)d.E * d.P;
+  const size_t i0 = ((blockIdx.x - emb_blocks) * (size_t)blockDim.x + threadIdx.x) * 4;
+  if (i0 >= n) return;
+  int e = (int)(i0 / d.P), q = (int)(i0 % d.P);
+  const bool plain = i0 + 4 <= n && q + 3 < d.P && q >= d.o_t1w && (q + 3 < emb_lo || q >= emb_hi);
+  if (plain) {   // all four trainable, of one member, none of them the embedder's
+    float4 p4 = *reinterpret_cast<const float4*>(d.params + i0), g4 = *reinterpret_cast<const float4*>(d.grads + i0);
+    float4 m4 = *reinterpret_cast<const float4*>(d.m + i0), v4 = *reinterpret_cast<const float4*>(d.v + i0);
+    adam_update(p4.x, m4.x, v4.x, g4.x, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+    adam_update(p4.y, m4.y, v4.y, g4.y, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+    adam_update(p4.z, m4.z, v4.z, g4.z, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+    adam_update(p4.w, m4.w, v4.w, g4.w, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+    *reinterpret_cast<float4*>(d.m + i0) = m4;
+    *reinterpret_cast<float4*>(d.v + i0) = v4;
+    *reinterpret_cast<float4*>(d.params + i0) = p4;
+  } else {
+    for (size_t i = i0; i < n && i < i0 + 4; ++i) {
+      // (GaussianFourierProjection.W, q < o_t1w: requires_grad=False)
+      if (q >= d.o_t1w && !(q >= emb_lo && q < emb_hi))
+        adam_update(d.params[i], d.m[i], d.v[i], d.grads[i], lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+      if (++q == d.P) { q = 0; ++e; }
+    }
+  }
 }
 
 }  // namespace
@@ -459,8 +502,11 @@ static int trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, 
   // torch/optim/adam.py _single_tensor_adam: the scalars are formed in double, applied to fp32 tensors
   const double bc1 = 1.0 - pow(beta1, (double)t->step), bc2 = 1.0 - pow(beta2, (double)t->step);
   const size_t n = (size_t)d.E * d.P;
-  hipLaunchKernelGGL(tr_adam, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, d, (float)(lr / bc1), (float)sqrt(bc2),
-                     (float)beta1, (float)beta2, (float)eps);
+  const int main_blocks = (int)((n + 1023) / 1024);
+  const int n_emb = (d.o_b0 < d.o_w0 ? d.o_b0 : d.o_w0) - d.o_ew;
+  const int emb_blocks = (d.E * n_emb + 255) / 256;
+  hipLaunchKernelGGL(tr_adam, dim3((unsigned)(main_blocks + emb_blocks)), dim3(256), 0, s, d, emb_blocks,
+                     (float)(lr / bc1), (float)sqrt(bc2), (float)beta1, (float)beta2, (float)eps);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }
