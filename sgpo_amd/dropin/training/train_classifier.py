@@ -50,33 +50,53 @@ def train_classifier_ensemble(classifiers, model, dataloader, train_config, save
         generator.manual_seed(int(torch.initial_seed()) & 0x7FFFFFFF)
     T = int(model.timestep) if time_conditioned else 1
     # Batches are prepared a group at a time (gather, timesteps, q_sample, project_fn over up to 64 batches per member
-    # in one call each), so that a step costs a slice and the five training launches instead of a dozen small torch
-    # kernels.  Every sequence still gets its own timestep and noise, every member its own order.
+    # in one call each -- and, when an epoch is shorter than that, over several epochs at once), so that a step costs a
+    # slice and the five training launches instead of a dozen small torch kernels.  Every sequence still gets its own
+    # timestep and noise, every member its own order in every epoch.
     group = 64 * bs
-    for _ in range(int(n_epochs)):
-        perm = torch.stack([torch.randperm(n, device=device, generator=generator) for _ in range(E)])   # shuffle=True
-        for g0 in range(0, n, group):
-            idx = perm[:, g0:g0 + group]                              # (E, G)
-            G = idx.shape[1]
-            x = X[idx]                                                # (E, G, L)
-            y = Y[idx]
-            if time_conditioned:
-                t = torch.randint(0, T, (E, G), device=device, generator=generator)       # train_classifier.py:36
-                xt = model.q_sample(x.reshape(E * G, Lq), t.reshape(E * G)).reshape(E, G, Lq)   # :13
-            else:
-                t = torch.zeros(E, G, dtype=torch.int64, device=device)                   # :38
-                xt = x
-            if project_fn is not None:
-                xt = project_fn(xt)                                                       # :14
-            tf = t.float()
-            nb = G // bs                                              # full batches, laid out (batch, member, row)
-            if nb:
-                xb = xt[:, :nb * bs].reshape(E, nb, bs, Lq).transpose(0, 1).contiguous()
-                tb = tf[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
-                yb = y[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
-                trainer.steps(xb, tb, yb, lr=lr)                  # the nb full batches, one library call
-            if G > nb * bs:                                           # the ragged last batch (drop_last=False)
-                trainer.step(xt[:, nb * bs:].contiguous(), tf[:, nb * bs:].contiguous(), y[:, nb * bs:].contiguous(), lr=lr)
+
+    def run_group(idx):                                               # idx: (E, G) rows of the data set, in batch order
+        G = idx.shape[1]
+        x = X[idx]                                                    # (E, G, L)
+        y = Y[idx]
+        if time_conditioned:
+            t = torch.randint(0, T, (E, G), device=device, generator=generator)           # train_classifier.py:36
+            xt = model.q_sample(x.reshape(E * G, Lq), t.reshape(E * G)).reshape(E, G, Lq)       # :13
+        else:
+            t = torch.zeros(E, G, dtype=torch.int64, device=device)                       # :38
+            xt = x
+        if project_fn is not None:
+            xt = project_fn(xt)                                                           # :14
+        return xt, t.float(), y
+
+    def run_batches(xt, tf, y):                                       # one epoch's (or one group's) rows of every member
+        G = xt.shape[1]
+        nb = G // bs                                                  # full batches, laid out (batch, member, row)
+        if nb:
+            xb = xt[:, :nb * bs].reshape(E, nb, bs, Lq).transpose(0, 1).contiguous()
+            tb = tf[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
+            yb = y[:, :nb * bs].reshape(E, nb, bs).transpose(0, 1).contiguous()
+            trainer.steps(xb, tb, yb, lr=lr)                          # the nb full batches, one library call
+        if G > nb * bs:                                               # the ragged last batch (drop_last=False)
+            trainer.step(xt[:, nb * bs:].contiguous(), tf[:, nb * bs:].contiguous(), y[:, nb * bs:].contiguous(), lr=lr)
+
+    def shuffles(k):                                                  # k epochs x E members: shuffle=True, one sort
+        return torch.rand(k, E, n, device=device, generator=generator).argsort(dim=-1)
+
+    done, n_epochs = 0, int(n_epochs)
+    while done < n_epochs:
+        if n <= group:
+            k = max(1, min(n_epochs - done, group // n, 262144 // max(1, E * n)))
+            perm = shuffles(k)                                        # (k, E, n)
+            xt, tf, y = run_group(perm.permute(1, 0, 2).reshape(E, k * n))
+            for j in range(k):                                        # epoch by epoch: the ragged batch ends each one
+                run_batches(xt[:, j * n:(j + 1) * n], tf[:, j * n:(j + 1) * n], y[:, j * n:(j + 1) * n])
+        else:
+            k = 1
+            perm = shuffles(1)[0]
+            for g0 in range(0, n, group):
+                run_batches(*run_group(perm[:, g0:g0 + group]))
+        done += k
     for c, sd in zip(classifiers, trainer.state_dicts()):
         c.model.load_state_dict(sd)
     if save_dir is not None:
