@@ -1,14 +1,15 @@
 // Row f-3: value-function ensemble training (training/train_classifier.py:7-64 -- Adam on the MSE of
 // MLPModel, problem/protein.py:58-121), all ensemble members in lockstep, five launches per optimiser step.
-//   tr_fwd0   grid (chunks, members): one 64-wide input chunk (a residue's embedding, or the time embedding)
-//             times its slice of mlp.0.weight -> partial pre-activations
+//   tr_fwd0   grid (chunk groups, members): two 64-wide input chunks (a residue's embedding each, or the time
+//             embedding) times their slices of mlp.0.weight, summed in the MFMA accumulators -> partial pre-activations
 //   tr_reduce grid over (member, row, unit): ordered sum of the partials + bias
 //   tr_mid    grid (members): the four 64x64 layers + head forward, MSE, and the
 //             backward pass down to d(pre-activation of mlp.0); activations live in LDS
 //   tr_bwd0   grid (chunks, members): gradient of the mlp.0.weight slice, of the chunk's input, and through the
 //             embedder (per-chunk partial sums per token) or the time embedder
 //   tr_adam   grid over all parameters: ordered sum of the embedder partials, torch.optim.Adam's update
-// fp32 throughout, every reduction in a fixed order (no atomics): a run is reproducible bit for bit.
+// fp32 throughout (the 64x64x64 products on the matrix cores), every reduction in a fixed order (no atomics): a run
+// is reproducible bit for bit.
 #include "common.h"
 #include <new>
 
@@ -57,6 +58,13 @@ __device__ __forceinline__ f32x16 mfma64(FA a_at, FB b_at, float init) {
   for (int k = 0; k < H; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_at(m, k + kh), b_at(k + kh, n), acc, 0, 0, 0);
   return acc;
 }
+template <class FA, class FB>
+__device__ __forceinline__ void mfma64_acc(FA a_at, FB b_at, f32x16& acc) {   // acc += A B
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const int m = (w >> 1) * 32 + (lane & 31), n = (w & 1) * 32 + (lane & 31), kh = lane >> 5;
+#pragma unroll 8
+  for (int k = 0; k < H; k += 2) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a_at(m, k + kh), b_at(k + kh, n), acc, 0, 0, 0);
+}
 template <class F>
 __device__ __forceinline__ void quad_store(const f32x16& acc, F put) {   // put(row, col, value)
   const Quad q = quad_of_lane();
@@ -85,20 +93,27 @@ __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const 
     }
   } else {
     const float* tw = p + d.o_tw;
-    for (int idx = tid; idx < TB * H; idx += 256) {
-      const int b = idx >> 6, j = idx & 63;
-      float f = 0.f;
-      if (b < B) {
-        // GaussianFourierProjection (problem/protein.py:54-56): x*W*2*pi, cat(sin, cos)
-        if (write_f) {
-          const float arg = t[(size_t)e * B + b] * tw[j & 31] * 2.0f * 3.14159274101257324f;
-          f = (j < 32) ? sinf(arg) : cosf(arg);
-          d.fbuf[((size_t)e * TB + b) * H + j] = f;
-        } else {
-          f = d.fbuf[((size_t)e * TB + b) * H + j];   // the backward pass reads what the forward pass stored
+    if (write_f) {
+      // GaussianFourierProjection (problem/protein.py:54-56): x*W*2*pi, cat(sin, cos).  One sincosf per argument
+      // (sin lands in column j, cos in column j + 32): the arguments are large (t W 2 pi up to ~1e4), so the range
+      // reduction is the cost, and a sinf and a cosf per argument would do it twice.
+      for (int idx = tid; idx < TB * (H / 2); idx += 256) {
+        const int b = idx >> 5, j = idx & 31;
+        float sn = 0.f, cs = 0.f;
+        if (b < B) {
+          const float arg = t[(size_t)e * B + b] * tw[j] * 2.0f * 3.14159274101257324f;
+          sincosf(arg, &sn, &cs);
+          d.fbuf[((size_t)e * TB + b) * H + j] = sn;
+          d.fbuf[((size_t)e * TB + b) * H + j + 32] = cs;
         }
+        tmp[b][j] = sn;
+        tmp[b][j + 32] = cs;
       }
-      tmp[b][j] = f;
+    } else {
+      for (int idx = tid; idx < TB * H; idx += 256) {
+        const int b = idx >> 6, j = idx & 63;
+        tmp[b][j] = b < B ? d.fbuf[((size_t)e * TB + b) * H + j] : 0.f;   // the backward pass reads what the forward pass stored
+      }
     }
     // Linear(64, 64) of the time embedder.  Its weight goes through `in` (row j read by lane j) before `in` takes
     // the result: read straight from memory, lane j walking row j is 64 cache lines per load instruction, and the one
@@ -114,52 +129,62 @@ __device__ void chunk_input(const TrDev& d, const float* p, int e, int c, const 
   }
 }
 
+constexpr int FWD_CHUNKS = 2;   // input chunks per tr_fwd0 workgroup, summed in the MFMA accumulators (1: 29 + 8 us for forward + reduce, two rounds of workgroups; 4: 38 + 5, the chain per workgroup is too long)
+
 __global__ __launch_bounds__(256) void tr_fwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
   __shared__ float in[TB][PAD], ws[H][PAD];
-  const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
+  const int n_groups = gridDim.x;
+  const int grp = (blockIdx.x + n_groups - 1) % n_groups, e = blockIdx.y, tid = threadIdx.x;   // the group with the (heavier) time chunk, the last one, is dispatched first
   const float* p = d.params + (size_t)e * d.P;
-  // the weight slice is requested before the input chunk is gathered (token -> embedding is two dependent loads):
-  // one memory latency for both instead of one after the other
-  const float* w0 = p + d.o_w0 + (size_t)c * H;
+  const int c0 = grp * FWD_CHUNKS, c1 = c0 + FWD_CHUNKS < d.C ? c0 + FWD_CHUNKS : d.C;
+  // a weight slice is requested before the input chunk is gathered (token -> embedding is two dependent loads), the
+  // next chunk's before this chunk's product: one memory latency per chunk instead of three
   float wreg[H * H / 256];
+  auto request_w = [&](int c) {
+    const float* w0 = p + d.o_w0 + (size_t)c * H;
 #pragma unroll
-  for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; wreg[it] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)]; }
-  chunk_input(d, p, e, c, x, t, B, L, in, ws, true);
-  __syncthreads();
+    for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; wreg[it] = w0[(size_t)(idx >> 6) * d.D + (idx & 63)]; }
+  };
+  request_w(c0);
+  f32x16 acc;
 #pragma unroll
-  for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; ws[idx >> 6][idx & 63] = wreg[it]; }
-  __syncthreads();
-  // partial pre-activation: out[b][o] = sum_k in[b][k] W0[o][c * 64 + k]
-  const f32x16 acc = mfma64([&](int m, int k) { return in[m][k]; }, [&](int k, int n) { return ws[n][k]; }, 0.f);
-  float* out = d.part_h + (((size_t)e * d.C + c) * TB) * H;
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  for (int c = c0; c < c1; ++c) {
+    chunk_input(d, p, e, c, x, t, B, L, in, ws, true);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < H * H / 256; ++it) { const int idx = tid + it * 256; ws[idx >> 6][idx & 63] = wreg[it]; }
+    if (c + 1 < c1) request_w(c + 1);
+    __syncthreads();
+    // partial pre-activation: out[b][o] += sum_k in[b][k] W0[o][c * 64 + k]
+    mfma64_acc([&](int m, int k) { return in[m][k]; }, [&](int k, int n) { return ws[n][k]; }, acc);
+    __syncthreads();
+  }
+  float* out = d.part_h + (((size_t)e * n_groups + grp) * TB) * H;
   quad_store(acc, [&](int b, int o, float v) { out[b * H + o] = v; });
 }
 
-// ordered sum of the chunk partials + bias -> pre-activation of mlp.0 (written over chunk 0's slot)
-__global__ void tr_reduce(TrDev d, int B) {
+// ordered sum of the chunk-group partials + bias -> pre-activation of mlp.0 (written over group 0's slot)
+__global__ void tr_reduce(TrDev d, int B, int n_groups) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;   // (e, b, o)
   if (i >= d.E * TB * H) return;
   const int e = i / (TB * H), bo = i % (TB * H), b = bo >> 6, o = bo & 63;
   if (b >= B) return;
-  float* ph = d.part_h + (size_t)e * d.C * TB * H;
+  float* ph = d.part_h + (size_t)e * n_groups * TB * H;
   float s = d.params[(size_t)e * d.P + d.o_b0 + o];
   int c = 0;
-  for (; c + 8 <= d.C; c += 8) {   // eight loads in flight, adds in chunk order
+  for (; c + 8 <= n_groups; c += 8) {   // eight loads in flight, adds in group order
     float v8[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) v8[u] = ph[(size_t)(c + u) * TB * H + bo];
 #pragma unroll
     for (int u = 0; u < 8; ++u) s += v8[u];
   }
-  for (; c < d.C; ++c) s += ph[(size_t)c * TB * H + bo];
+  for (; c < n_groups; ++c) s += ph[(size_t)c * TB * H + bo];
   ph[bo] = s;
 }
 
 // ---- block-level 64-wide layer helpers (256 threads, rows >= B hold zeros) ----
-__device__ void load_w(float (*wb)[PAD], const float* w) {
-  for (int idx = threadIdx.x; idx < H * H; idx += 256) wb[idx >> 6][idx & 63] = w[idx];
-  __syncthreads();
-}
 // out[b][o] = act(bias[o] + sum_k in[b][k] W[o][k])
 __device__ void lin_fwd(float (*out)[PAD], float (*in)[PAD], float (*wb)[PAD], const float* bias, bool relu, int B) {
   const f32x16 acc = mfma64([&](int m, int k) { return in[m][k]; }, [&](int k, int n) { return wb[n][k]; }, bias[quad_of_lane().col]);
@@ -191,23 +216,31 @@ __device__ void grad_in(float (*da)[PAD], float (*dz)[PAD], float (*wb)[PAD], fl
   __syncthreads();
 }
 
-__global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__ y, int B, float* __restrict__ loss_out) {
+__global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__ y, int B, int n_groups, float* __restrict__ loss_out) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   float (*a0)[PAD] = reinterpret_cast<float (*)[PAD]>(smem_raw);
   float (*a1)[PAD] = a0 + TB;
   float (*a2)[PAD] = a1 + TB;
   float (*a3)[PAD] = a2 + TB;
-  float (*wb)[PAD] = a3 + TB;
-  float (*g0)[PAD] = wb + H;
+  float (*w1)[PAD] = a3 + TB;        // mlp.2, mlp.4, cls_head.0: loaded once, used by the forward and the backward pass
+  float (*w2)[PAD] = w1 + H;
+  float (*w3)[PAD] = w2 + H;
+  float (*g0)[PAD] = w3 + H;
   float (*g1)[PAD] = g0 + TB;
   float* pred = reinterpret_cast<float*>(g1 + TB);   // [TB]
   float* dpred = pred + TB;                          // [TB]
   const int e = blockIdx.x, tid = threadIdx.x;
   const float* p = d.params + (size_t)e * d.P;
   float* g = d.grads + (size_t)e * d.P;
+  // the three 64 x 64 weights in one go (one memory latency instead of one per use), then
   // pre-activation of mlp.0 (tr_reduce left it in chunk 0's slot) -> ReLU
+  for (int idx = tid; idx < H * H; idx += 256) {
+    w1[idx >> 6][idx & 63] = p[d.o_w1 + idx];
+    w2[idx >> 6][idx & 63] = p[d.o_w2 + idx];
+    w3[idx >> 6][idx & 63] = p[d.o_c0 + idx];
+  }
   {
-    const float* ph = d.part_h + (size_t)e * d.C * TB * H;
+    const float* ph = d.part_h + (size_t)e * n_groups * TB * H;
     for (int idx = tid; idx < TB * H; idx += 256) {
       const int b = idx >> 6, o = idx & 63;
       float s = 0.f;
@@ -219,9 +252,9 @@ __global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__
     }
     __syncthreads();
   }
-  load_w(wb, p + d.o_w1); lin_fwd(a1, a0, wb, p + d.o_b1, true, B);
-  load_w(wb, p + d.o_w2); lin_fwd(a2, a1, wb, p + d.o_b2, false, B);
-  load_w(wb, p + d.o_c0); lin_fwd(a3, a2, wb, p + d.o_c0b, true, B);
+  lin_fwd(a1, a0, w1, p + d.o_b1, true, B);
+  lin_fwd(a2, a1, w2, p + d.o_b2, false, B);
+  lin_fwd(a3, a2, w3, p + d.o_c0b, true, B);
   // head + MSE (criterion = MSELoss(): mean over the batch)
   const float* c2 = p + d.o_c2;
   if (tid < TB) {
@@ -255,11 +288,11 @@ __global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__
   }
   __syncthreads();
   grad_w(g + d.o_c0, g + d.o_c0b, g0, a2, B);          // cls_head.0
-  load_w(wb, p + d.o_c0); grad_in(g1, g0, wb, a2, false, B);   // d a2 (mlp.4 has no ReLU after it)
+  grad_in(g1, g0, w3, a2, false, B);                   // d a2 (mlp.4 has no ReLU after it)
   grad_w(g + d.o_w2, g + d.o_b2, g1, a1, B);           // mlp.4
-  load_w(wb, p + d.o_w2); grad_in(g0, g1, wb, a1, true, B);    // d z of mlp.2
+  grad_in(g0, g1, w2, a1, true, B);                    // d z of mlp.2
   grad_w(g + d.o_w1, g + d.o_b1, g0, a0, B);           // mlp.2
-  load_w(wb, p + d.o_w1); grad_in(g1, g0, wb, a0, true, B);    // d pre-activation of mlp.0
+  grad_in(g1, g0, w1, a0, true, B);                    // d pre-activation of mlp.0
   float* dh = d.dh + (size_t)e * TB * H;
   for (int idx = tid; idx < TB * H; idx += 256) dh[idx] = g1[idx >> 6][idx & 63];
   if (tid < H) {
@@ -394,7 +427,7 @@ __global__ __launch_bounds__(256) void tr_adam(TrDev d, int emb_blocks, float lr
   const size_t n = (size_t)d.E * d.P;
   const size_t i0 = ((blockIdx.x - emb_blocks) * (size_t)blockDim.x + threadIdx.x) * 4;
   if (i0 >= n) return;
-  int e = (int)(i0 / d.P), q = (int)(i0 % d.P);
+  int q = (int)(i0 % d.P);
   const bool plain = i0 + 4 <= n && q + 3 < d.P && q >= d.o_t1w && (q + 3 < emb_lo || q >= emb_hi);
   if (plain) {   // all four trainable, of one member, none of them the embedder's
     float4 p4 = *reinterpret_cast<const float4*>(d.params + i0), g4 = *reinterpret_cast<const float4*>(d.grads + i0);
@@ -411,7 +444,7 @@ __global__ __launch_bounds__(256) void tr_adam(TrDev d, int emb_blocks, float lr
       // (GaussianFourierProjection.W, q < o_t1w: requires_grad=False)
       if (q >= d.o_t1w && !(q >= emb_lo && q < emb_hi))
         adam_update(d.params[i], d.m[i], d.v[i], d.grads[i], lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
-      if (++q == d.P) { q = 0; ++e; }
+      if (++q == d.P) q = 0;
     }
   }
 }
@@ -484,7 +517,7 @@ extern "C" int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_
   HIPF(hipMemset(d.m, 0, EP * 4));
   HIPF(hipMemset(d.v, 0, EP * 4));
   t->step = 0;
-  t->mid_lds = (size_t)(4 * TB + H + 2 * TB) * PAD * 4 + 2 * TB * 4;
+  t->mid_lds = (size_t)(4 * TB + 3 * H + 2 * TB) * PAD * 4 + 2 * TB * 4;   // 150 KB
   HIPF(hipFuncSetAttribute(reinterpret_cast<const void*>(tr_mid), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t->mid_lds));
 #undef HIPF
   *out = t;
@@ -494,9 +527,10 @@ extern "C" int sgpo_mlp_trainer_create(const float* blobs, int n_members, int n_
 static int trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, const float* y, int B, int L, double lr,
                         double beta1, double beta2, double eps, float* loss_out, hipStream_t s) {
   const TrDev& d = t->d;
-  hipLaunchKernelGGL(tr_fwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);
-  hipLaunchKernelGGL(tr_reduce, dim3((d.E * TB * H + 255) / 256), dim3(256), 0, s, d, B);
-  hipLaunchKernelGGL(tr_mid, dim3(d.E), dim3(256), t->mid_lds, s, d, y, B, loss_out);
+  const int n_groups = (d.C + FWD_CHUNKS - 1) / FWD_CHUNKS;
+  hipLaunchKernelGGL(tr_fwd0, dim3(n_groups, d.E), dim3(256), 0, s, d, x, tt, B, L);
+  hipLaunchKernelGGL(tr_reduce, dim3((d.E * TB * H + 255) / 256), dim3(256), 0, s, d, B, n_groups);
+  hipLaunchKernelGGL(tr_mid, dim3(d.E), dim3(256), t->mid_lds, s, d, y, B, n_groups, loss_out);
   hipLaunchKernelGGL(tr_bwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);
   t->step += 1;
   // torch/optim/adam.py _single_tensor_adam: the scalars are formed in double, applied to fp32 tensors
