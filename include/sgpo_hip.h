@@ -142,6 +142,21 @@ int sgpo_guidance_ratio_mlp(sgpo_mlp* m, const int64_t* x, float t, int B, int L
  * and the mask column everywhere, are bit-identical to sgpo_guidance_ratio_mlp).  Same workspace. */
 int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index,
                                       float* log_ratio, void* workspace, size_t workspace_bytes, void* stream);
+/* One guided step (cls_guidance.py:34-52) for SEVERAL sampler calls stacked in one batch, e.g. the Thompson draws of
+ * iterativeBO.py:204-237 (`update_model(member); inference(10)` per draw): rows [row_lo[g], row_lo[g+1]) belong to
+ * draw g with value function members[g] (NULL: unguided) and Philox key (seeds[g], offsets[g], row_offsets[g] -- the
+ * arguments sgpo_reverse_step_mdlm would get for that draw alone).  The kernels of sgpo_guidance_ratio_mlp_absorbing
+ * and of sgpo_reverse_step_mdlm (SGPO_STEP_SOFT_CG, in-kernel Philox) run once for up to 16 draws at a time; inside a
+ * draw every index is that of its own call, so every draw gets the tokens of its own call, bit for bit.  The value
+ * functions must read the same positions.  members, row_lo (n_groups + 1, row_lo[0] = 0), seeds, offsets, row_offsets
+ * are HOST arrays.  log_ratio / workspace: device scratch for all B = row_lo[n_groups] rows, B * n_read * S floats and
+ * sgpo_mlp_workspace_bytes(m, B) bytes.  logits [B][L][K], x and x_out [B][L]. */
+int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* members, const int* row_lo, const float* logits,
+                                 const int64_t* x, int L, int K, int S, float t, int mask_index, float move_chance_t,
+                                 float move_chance_s, float guide_temp, const uint64_t* seeds, const uint64_t* offsets,
+                                 const uint64_t* row_offsets, const int* slot_of_pos, float* log_ratio,
+                                 size_t log_ratio_bytes, void* workspace, size_t workspace_bytes, int64_t* x_out,
+                                 int* nan_flag, void* stream);
 /* sgpo_guidance_ratio_mlp_absorbing for callers that cannot allocate.  No counterpart in the reference: it is for
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc, which have no way to
  * provide the workspace.  Same arguments minus the workspace, same kernels, same bits in log_ratio.  The

@@ -46,6 +46,8 @@ SIGNATURES = {
     'sgpo_mlp_workspace_bytes': (_sz, [_vp, _i]),
     'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sgpo_guidance_ratio_mlp_absorbing': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
+    'sgpo_guided_step_groups_mdlm': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz,
+                                          _vp, _sz, _vp, _vp, _vp]),
     'sgpo_guidance_noalloc_max_bytes': (_sz, []),
     'sgpo_guidance_ratio_mlp_absorbing_noalloc': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     'sgpo_fitness_create': (_i, [_vp, _sz, _i, _i, _i, C.POINTER(_vp)]),

@@ -140,12 +140,12 @@ struct MlpDev {
 
 // lists (absorbing-state compaction, mask_index >= 0): per sequence cnt[2] = {#masked, #unmasked read slots},
 // then the masked slots and the unmasked slots, each in increasing order (uint16 [2][n_read])
-__global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* __restrict__ x, const float* __restrict__ t,
-                                                      float t_scalar, int L, float* __restrict__ hpre,
-                                                      float* __restrict__ fout, int mask_index, int* __restrict__ cnt,
-                                                      unsigned short* __restrict__ lists) {
+__device__ __forceinline__ void mlp_base_body(const MlpDev& d, int b, const int64_t* __restrict__ x, const float* __restrict__ t,
+                                              float t_scalar, int L, float* __restrict__ hpre,
+                                              float* __restrict__ fout, int mask_index, int* __restrict__ cnt,
+                                              unsigned short* __restrict__ lists) {
   __shared__ float buf[2][MH];
-  const int b = blockIdx.x, j = threadIdx.x;
+  const int j = threadIdx.x;
   float pre = d.be1[j];
   if (d.time_cond) {
     const float tv = t ? t[b] : t_scalar;
@@ -214,6 +214,27 @@ __global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* _
   if (j == 0) fout[b] = a + d.b5[0];
 }
 
+__global__ __launch_bounds__(64) void mlp_base_kernel(MlpDev d, const int64_t* __restrict__ x, const float* __restrict__ t,
+                                                      float t_scalar, int L, float* __restrict__ hpre,
+                                                      float* __restrict__ fout, int mask_index, int* __restrict__ cnt,
+                                                      unsigned short* __restrict__ lists) {
+  mlp_base_body(d, blockIdx.x, x, t, t_scalar, L, hpre, fout, mask_index, cnt, lists);
+}
+
+// several stacked draws (mlp.h): blockIdx.y picks the draw and its value function, blockIdx.x a sequence of it; the
+// shared buffers are indexed by the row of the stacked batch
+struct MlpGroups {
+  int seq_lo[SGPO_MAX_GROUPS], n_seq[SGPO_MAX_GROUPS];
+  MlpDev d[SGPO_MAX_GROUPS];
+};
+__global__ __launch_bounds__(64) void mlp_base_groups_kernel(MlpGroups gs, const int64_t* __restrict__ x, float t_scalar, int L,
+                                                             float* __restrict__ hpre, int mask_index, int* __restrict__ cnt,
+                                                             unsigned short* __restrict__ lists) {
+  const int g = blockIdx.y;
+  if ((int)blockIdx.x >= gs.n_seq[g]) return;
+  mlp_base_body(gs.d[g], gs.seq_lo[g] + blockIdx.x, x, nullptr, t_scalar, L, hpre, nullptr, mask_index, cnt, lists);
+}
+
 static MlpDev mlp_dev(const sgpo_mlp* m) {
   MlpDev d;
   d.read_pos = m->read_pos; d.T1 = m->T1; d.be1 = m->be1; d.w1t_time = m->w1t_time; d.wt_lin_t = m->wt_lin_t;
@@ -269,13 +290,13 @@ __device__ __forceinline__ void mfma_layer(const float* __restrict__ wl /*LDS [t
 // position whose token is not the mask, the prior rate is exactly 0 for every target except the mask and
 // the token itself (models/mdlm.py subs parameterisation + carry-over), so those are the only jumps that
 // can change the guided rates; the rest of the row stays at the zero the caller's memset left there.
-__global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restrict__ w_perm, const float* __restrict__ bias_perm,
-                                                       const float* __restrict__ T1, const int* __restrict__ read_pos,
-                                                       const float* __restrict__ hpre, const int64_t* __restrict__ x,
-                                                       float b5, int B, int n_read, int alphabet, int S, int L,
-                                                       int mask_index, const int* __restrict__ cnt,
-                                                       const unsigned short* __restrict__ lists, int spread,
-                                                       float* __restrict__ log_ratio) {
+__device__ __forceinline__ void mlp_jump_body(const float* __restrict__ w_perm, const float* __restrict__ bias_perm,
+                                              const float* __restrict__ T1, const int* __restrict__ read_pos,
+                                              const float* __restrict__ hpre, const int64_t* __restrict__ x,
+                                              float b5, int B, int n_read, int alphabet, int S, int L,
+                                              int mask_index, const int* __restrict__ cnt,
+                                              const unsigned short* __restrict__ lists, int spread,
+                                              float* __restrict__ log_ratio) {
   __shared__ float wl[3 * MH * MH];
   __shared__ float bl[4 * MH];
   for (int i = threadIdx.x; i < 3 * MH * MH; i += 256) wl[i] = w_perm[i];
@@ -370,6 +391,37 @@ __global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restric
   }
 }
 
+__global__ __launch_bounds__(256, 2) void mlp_jump_kernel(const float* __restrict__ w_perm, const float* __restrict__ bias_perm,
+                                                       const float* __restrict__ T1, const int* __restrict__ read_pos,
+                                                       const float* __restrict__ hpre, const int64_t* __restrict__ x,
+                                                       float b5, int B, int n_read, int alphabet, int S, int L,
+                                                       int mask_index, const int* __restrict__ cnt,
+                                                       const unsigned short* __restrict__ lists, int spread,
+                                                       float* __restrict__ log_ratio) {
+  mlp_jump_body(w_perm, bias_perm, T1, read_pos, hpre, x, b5, B, n_read, alphabet, S, L, mask_index, cnt, lists, spread, log_ratio);
+}
+
+// several stacked draws: blockIdx.y picks the draw; its rows of the shared buffers are addressed by offsetting the
+// pointers, so inside the draw every index is the one of its own launch
+struct JumpGroups {
+  int seq_lo[SGPO_MAX_GROUPS], n_seq[SGPO_MAX_GROUPS];
+  const float* w_perm[SGPO_MAX_GROUPS];
+  const float* bias_perm[SGPO_MAX_GROUPS];
+  const float* T1[SGPO_MAX_GROUPS];
+};
+__global__ __launch_bounds__(256, 2) void mlp_jump_groups_kernel(JumpGroups gs, const int* __restrict__ read_pos,
+                                                              const float* __restrict__ hpre, const int64_t* __restrict__ x,
+                                                              int n_read, int alphabet, int S, int L, int mask_index,
+                                                              const int* __restrict__ cnt, const unsigned short* __restrict__ lists,
+                                                              float* __restrict__ log_ratio) {
+  const int g = blockIdx.y;
+  const int lo = gs.seq_lo[g], n = gs.n_seq[g];
+  if (n <= 0) return;
+  mlp_jump_body(gs.w_perm[g], gs.bias_perm[g], gs.T1[g], read_pos, hpre + (size_t)lo * MH, x + (size_t)lo * L, 0.f, n, n_read,
+                alphabet, S, L, mask_index, cnt + 2 * lo, lists + (size_t)lo * 2 * n_read, n < 1024 ? 1 : 0,
+                log_ratio + (size_t)lo * n_read * S);
+}
+
 static size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 // hpre [B][64] f32 | cnt [B][2] i32 | lists [B][2][n_read] u16
@@ -428,6 +480,100 @@ extern "C" int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, 
                                                  float* log_ratio, void* workspace, size_t workspace_bytes, void* stream) {
   SGPO_REQUIRE(mask_index >= 0, "guidance_ratio_mlp_absorbing: mask_index %d", mask_index);
   return guidance_ratio(m, x, t, B, L, S, mask_index, log_ratio, workspace, workspace_bytes, stream);
+}
+
+// ---- one guided step for several stacked sampler calls -------------------------------------------------------------
+// Rows [row_lo[g], row_lo[g + 1]) of the batch belong to draw g, which has its own value function and its own Philox
+// key.  The kernels of sgpo_guidance_ratio_mlp_absorbing and sgpo_reverse_step_mdlm run ONCE for up to SGPO_MAX_GROUPS
+// draws (blockIdx.y picks the draw; inside a draw every index is that of its own launch, so the tokens are the same bit
+// for bit) instead of four small launches per draw: ten draws of ten sequences were forty launches a step, a quarter of
+// the step's GPU time and most of its launch gaps.
+extern "C" int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* members, const int* row_lo, const float* logits,
+                                            const int64_t* x, int L, int K, int S, float t, int mask_index,
+                                            float move_chance_t, float move_chance_s, float guide_temp,
+                                            const uint64_t* seeds, const uint64_t* offsets, const uint64_t* row_offsets,
+                                            const int* slot_of_pos, float* log_ratio, size_t log_ratio_bytes,
+                                            void* workspace, size_t workspace_bytes, int64_t* x_out, int* nan_flag,
+                                            void* stream) {
+  SGPO_REQUIRE(n_groups > 0 && members && row_lo && logits && x && seeds && offsets && row_offsets && x_out,
+               "guided_step_groups: null argument");
+  SGPO_REQUIRE(L > 0 && K > 0 && row_lo[0] >= 0, "guided_step_groups: L=%d K=%d first row %d", L, K, row_lo[0]);
+  hipStream_t st = (hipStream_t)stream;
+  const int B = row_lo[n_groups];
+  // the value functions of one call share the read positions (one slot map, one workspace layout over all B rows)
+  const sgpo_mlp* first = nullptr;
+  for (int g = 0; g < n_groups; ++g) {
+    SGPO_REQUIRE(row_lo[g + 1] > row_lo[g], "guided_step_groups: group %d has %d rows", g, row_lo[g + 1] - row_lo[g]);
+    const sgpo_mlp* m = (guide_temp != 0.f) ? members[g] : nullptr;
+    if (!m) continue;
+    if (!first) first = m;
+    SGPO_REQUIRE(m->n_read == first->n_read && m->alphabet == first->alphabet, "guided_step_groups: group %d reads %d positions over %d letters, group 0 %d over %d",
+                 g, m->n_read, m->alphabet, first->n_read, first->alphabet);
+    for (int i = 0; i < m->n_read; ++i)
+      SGPO_REQUIRE(m->read_pos_host[i] == first->read_pos_host[i], "guided_step_groups: group %d reads other positions than the first", g);
+  }
+  float* hpre = nullptr; int* cnt = nullptr; unsigned short* lists = nullptr;
+  if (first) {
+    SGPO_REQUIRE(log_ratio && workspace && mask_index >= 0 && mask_index < S && S > 0 && S <= 32 && S <= first->alphabet,
+                 "guided_step_groups: log_ratio/workspace missing or S=%d mask %d", S, mask_index);
+    SGPO_REQUIRE(first->n_read < 65536, "guided_step_groups: n_read %d", first->n_read);
+    if (int rc = check_read_pos(first, L, "guided_step_groups")) return rc;
+    const size_t need_lr = (size_t)B * first->n_read * S * sizeof(float), need_ws = sgpo_mlp_workspace_bytes(first, B);
+    if (log_ratio_bytes < need_lr || workspace_bytes < need_ws) {
+      sgpo_set_error("guided_step_groups: log_ratio %zu / workspace %zu bytes, need %zu / %zu for %d rows", log_ratio_bytes,
+                     workspace_bytes, need_lr, need_ws, B);
+      return SGPO_ERR_WORKSPACE;
+    }
+    char* w = (char*)workspace;
+    hpre = (float*)w;
+    cnt = (int*)(w + al256((size_t)B * MH * sizeof(float)));
+    lists = (unsigned short*)((char*)cnt + al256((size_t)B * 2 * sizeof(int)));
+    SGPO_CHECK_HIP(hipMemsetAsync(log_ratio, 0, need_lr, st));
+  }
+  for (int g0 = 0; g0 < n_groups; g0 += SGPO_MAX_GROUPS) {
+    const int ng = n_groups - g0 < SGPO_MAX_GROUPS ? n_groups - g0 : SGPO_MAX_GROUPS;
+    RsGroups rs{};
+    MlpGroups mg{};
+    JumpGroups jg{};
+    rs.n = ng;
+    int max_seq = 0, max_guided = 0;
+    double base_work = 0, jump_work = 0;
+    for (int i = 0; i < ng; ++i) {
+      const int g = g0 + i, lo = row_lo[g], n = row_lo[g + 1] - lo;
+      const sgpo_mlp* m = (guide_temp != 0.f) ? members[g] : nullptr;
+      rs.g[i] = RsGroup{lo, n, m ? 1 : 0, 0, seeds[g], offsets[g], row_offsets[g]};
+      mg.seq_lo[i] = jg.seq_lo[i] = lo;
+      mg.n_seq[i] = jg.n_seq[i] = m ? n : 0;
+      if (m) {
+        mg.d[i] = mlp_dev(m);
+        jg.w_perm[i] = m->w_perm; jg.bias_perm[i] = m->bias_perm; jg.T1[i] = m->T1;
+        if (n > max_guided) max_guided = n;
+        base_work += (double)n * m->n_read * MH * 4.0;
+        jump_work += (double)n * m->n_read * (3.0 * 2 * MH * MH + 5.0 * MH);
+      }
+      if (n > max_seq) max_seq = n;
+    }
+    if (max_guided > 0) {
+      {
+        ProfScope prof_scope(PK_MLP_BASE, st, base_work);
+        hipLaunchKernelGGL(mlp_base_groups_kernel, dim3(max_guided, ng), dim3(64), 0, st, mg, x, t, L, hpre, mask_index, cnt, lists);
+      }
+      const int spread = max_guided < 1024 ? 1 : 0;
+      const int n_units = spread ? max_guided * first->n_read : max_guided;
+      int blocks = (n_units + 3) / 4;
+      const int cap = (256 * 3 + ng - 1) / ng;   // about three resident blocks per CU over all draws, grid-stride the rest
+      if (blocks > cap) blocks = cap;
+      ProfScope prof_scope(PK_MLP_JUMP, st, jump_work);
+      hipLaunchKernelGGL(mlp_jump_groups_kernel, dim3(blocks, ng), dim3(256), 0, st, jg, first->read_pos, hpre, x,
+                         first->n_read, first->alphabet, S, L, mask_index, cnt, lists, log_ratio);
+    }
+    SGPO_CHECK_HIP(hipGetLastError());
+    if (int rc = launch_reverse_step_mdlm_groups(rs, max_seq, logits, x, first ? log_ratio : nullptr, first ? slot_of_pos : nullptr,
+                                                 first ? first->n_read : L, L, K, mask_index, move_chance_t, move_chance_s,
+                                                 guide_temp, x_out, nan_flag, st))
+      return rc;
+  }
+  return SGPO_OK;
 }
 
 // ---- the same call for callers that cannot allocate -----------------------------------------

@@ -19,3 +19,21 @@ struct sgpo_mlp {
   const float *W2, *W3, *W4;   // row-major [out][in] views into params
   const float *tW, *bt, *b2, *b3, *b4, *w5, *b5;
 };
+
+// ---- several stacked sampler calls in one launch (sgpo_guided_step_groups_mdlm) ----
+// A group is one draw: rows [seq_lo, seq_lo + n_seq) of the stacked batch, its own Philox key and (guidance kernels)
+// its own value function.  The kernels take up to SGPO_MAX_GROUPS of them by value and blockIdx.y picks one; inside a
+// group every index is the one the group's own launch would use, so the results are those of separate launches.
+#define SGPO_MAX_GROUPS 16
+struct RsGroup {
+  int seq_lo, n_seq, guided, pad_;
+  uint64_t seed, offset, row_offset;
+};
+struct RsGroups {
+  int n;   // 0: plain launch, the scalar arguments apply
+  RsGroup g[SGPO_MAX_GROUPS];
+};
+int launch_reverse_step_mdlm_groups(const RsGroups& gs, int max_seq, const float* logits, const int64_t* x,
+                                    const float* log_ratio, const int* slot_of_pos, int n_slots, int L, int K,
+                                    int mask_index, float move_chance_t, float move_chance_s, float guide_temp,
+                                    int64_t* x_out, int* nan_flag, hipStream_t stream);

@@ -13,6 +13,7 @@
 #include "../../include/sgpo_hip.h"
 #include "common.h"
 #include "prof.h"
+#include "mlp.h"
 
 #define NEG_INF_REF (-1000000.0f)
 
@@ -148,7 +149,14 @@ __global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
     const int* __restrict__ slot_of_pos, int n_slots, int rows, int L, int K, int mask_index, float mt, float ms,
     float guide_temp, int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed,
     uint64_t offset, uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out,
-    int* __restrict__ nan_flag) {
+    int* __restrict__ nan_flag, RsGroups gs) {
+  if (gs.n > 0) {   // grouped launch: blockIdx.y is a draw of the stacked batch, with its own rows and Philox key
+    const RsGroup& G = gs.g[blockIdx.y];
+    const size_t r0 = (size_t)G.seq_lo * L;
+    logits += r0 * K; x += r0; x_out += r0;
+    log_ratio = G.guided ? log_ratio + (size_t)G.seq_lo * n_slots * K : nullptr;
+    rows = G.n_seq * L; seed = G.seed; offset = G.offset; row_offset = G.row_offset;
+  }
   const int half = (blockIdx.x * 256 + threadIdx.x) >> 5;
   const int k = threadIdx.x & 31;
   const int row0 = half * RS_ROWS;
@@ -223,7 +231,28 @@ extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, con
                        (double)rows * (K * 4.0 * ((log_ratio && guide_temp != 0.f && step_mode == SGPO_STEP_SOFT_CG) ? 2 : 1) + 16.0));
   hipLaunchKernelGGL(reverse_step_mdlm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, x, log_ratio,
                      slot_of_pos, n_slots, rows, L, K, mask_index, move_chance_t, move_chance_s, guide_temp, step_mode,
-                     noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag);
+                     noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag, RsGroups{});
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// the classifier-guidance step of several stacked draws in one launch (in-kernel Philox; see mlp.h)
+int launch_reverse_step_mdlm_groups(const RsGroups& gs, int max_seq, const float* logits, const int64_t* x,
+                                    const float* log_ratio, const int* slot_of_pos, int n_slots, int L, int K,
+                                    int mask_index, float move_chance_t, float move_chance_s, float guide_temp,
+                                    int64_t* x_out, int* nan_flag, hipStream_t stream) {
+  SGPO_REQUIRE(gs.n > 0 && gs.n <= SGPO_MAX_GROUPS && logits && x && x_out, "reverse_step_mdlm_groups: bad arguments");
+  SGPO_REQUIRE(L > 0 && K > 0 && K <= 32 && mask_index >= 0 && mask_index < K, "reverse_step_mdlm_groups: L=%d K=%d mask %d", L, K, mask_index);
+  SGPO_REQUIRE(log_ratio == nullptr || slot_of_pos != nullptr || n_slots == L, "reverse_step_mdlm_groups: n_slots must equal L without a slot map");
+  const int rows = max_seq * L;
+  const int blocks = ((rows + RS_ROWS - 1) / RS_ROWS + 7) / 8;
+  double total = 0;
+  for (int g = 0; g < gs.n; ++g) total += (double)gs.g[g].n_seq * L * (K * 4.0 * ((gs.g[g].guided && guide_temp != 0.f) ? 2 : 1) + 16.0);
+  ProfScope prof_scope(PK_REVERSE_STEP, stream, total);
+  hipLaunchKernelGGL(reverse_step_mdlm_kernel, dim3(blocks, gs.n), dim3(256), 0, stream, logits, x, log_ratio, slot_of_pos,
+                     n_slots, 0, L, K, mask_index, move_chance_t, move_chance_s, guide_temp, SGPO_STEP_SOFT_CG,
+                     SGPO_NOISE_PHILOX, (const float*)nullptr, (uint64_t)0, (uint64_t)0, (uint64_t)0, x_out, (float*)nullptr,
+                     nan_flag, gs);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }

@@ -278,6 +278,11 @@ class MDLM(GenerativeModel):
         mt, ms, sig_t = self._move_chances(t)
         logits = self._denoise(x, sig_t)
         x_out = torch.empty_like(x)
+        fused = self._fused_groups(groups, x.shape[1]) if self.diffusion == 'absorbing_state' else None
+        if fused is not None:      # every group's value function lives in the library: one call steps them all
+            runner, slots = fused
+            return runner.step(logits.contiguous(), x.contiguous(), float(t), mt, ms, self.model.mask_index, guide_temp,
+                               slots, self._nan_flag, x_out)
         for pred, src, lo, hi in groups:
             xs = x[lo:hi]
             lr = slots = None
@@ -287,6 +292,32 @@ class MDLM(GenerativeModel):
                                  log_ratio=lr, slot_of_pos=slots, guide_temp=guide_temp, nan_flag=self._nan_flag,
                                  x_out=x_out[lo:hi])
         return x_out
+
+    def _fused_groups(self, groups, Lq):
+        """(rt.GuidedStepGroups, slot map) for `groups` if each predictor offers `hip_value_function` (or is None) and
+        the row ranges are consecutive from 0; None otherwise.  Cached on the groups list of a run."""
+        cache = self.__dict__.setdefault('_groups_cache', {})
+        key = id(groups)
+        hit = cache.get(key)
+        if hit is not None and hit[0] is groups:
+            return hit[1]
+        out = None
+        vfs = []
+        ok = groups[0][2] == 0 and all(groups[i][3] == groups[i + 1][2] for i in range(len(groups) - 1))
+        for pred, _, _, _ in groups:
+            vf = getattr(pred, 'hip_value_function', None) if pred is not None else None
+            if pred is not None and vf is None:
+                ok = False
+                break
+            vfs.append(vf() if vf is not None else None)
+        live = [v for v in vfs if v is not None]
+        if ok and all(v.read_pos == live[0].read_pos for v in live):
+            runner = rt.GuidedStepGroups([(v, src, lo, hi) for v, (_, src, lo, hi) in zip(vfs, groups)], self.S, self._dev)
+            slots = _slot_map(live[0].read_pos, Lq, self._dev) if live else None
+            out = (runner, slots)
+        cache.clear()              # one live run at a time; the entry keeps `groups` alive so its id stays unique
+        cache[key] = (groups, out)
+        return out
 
     def check_nan(self):
         """The reference's two failure modes of a guided step, read back from the kernel's flag: NaN rates

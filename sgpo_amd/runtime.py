@@ -480,6 +480,47 @@ def reverse_step_mdlm(logits, x, mt, ms, mask_index, step_mode, noise_src=None, 
     return x_out, probs
 
 
+class GuidedStepGroups:
+    """Stacked sampler calls (Thompson draws) stepped through `sgpo_guided_step_groups_mdlm`: the per-group host arrays
+    are built once, a step only refreshes the Philox call offsets.  groups: [(MlpValueFunction | None, NoiseSource, lo, hi)]
+    with consecutive row ranges."""
+
+    def __init__(self, groups, S, device):
+        self.lib = L.load()
+        self.groups = groups
+        n = len(groups)
+        assert n > 0 and all(groups[i][3] == groups[i + 1][2] for i in range(n - 1)), 'row ranges must be consecutive'
+        vfs = [g[0] for g in groups if g[0] is not None]
+        self.read_pos = vfs[0].read_pos if vfs else None
+        assert all(v.read_pos == self.read_pos for v in vfs), 'stacked value functions must read the same positions'
+        self.members = (C.c_void_p * n)(*[getattr(g[0].handle, 'value', g[0].handle) if g[0] is not None else None for g in groups])
+        self.row_lo = (C.c_int * (n + 1))(*([g[2] for g in groups] + [groups[-1][3]]))
+        self.seeds = (C.c_uint64 * n)(*[g[1].seed for g in groups])
+        self.offsets = (C.c_uint64 * n)()
+        self.n = n
+        self.S = S
+        rows = groups[-1][3]            # the scratch buffers cover the whole stacked batch
+        self.ws_bytes = max([int(self.lib.sgpo_mlp_workspace_bytes(v.handle, rows)) for v in vfs] or [0]) + 256
+        self.lr_bytes = rows * (len(self.read_pos) if vfs else 0) * S * 4
+        self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=device)
+        self.lr = torch.empty(max(self.lr_bytes, 4), dtype=torch.uint8, device=device)
+
+    def step(self, logits, x, t, mt, ms, mask_index, guide_temp, slot_of_pos, nan_flag, x_out):
+        B, Lq, K = logits.shape
+        assert logits.is_contiguous() and x.is_contiguous() and x_out.is_contiguous()
+        assert self.row_lo[0] == 0 and self.row_lo[self.n] == B
+        row_offsets = (C.c_uint64 * self.n)(*[g[1].row_offset * Lq for g in self.groups])
+        for i, g in enumerate(self.groups):
+            self.offsets[i] = g[1].next_offset()
+        base = (self.ws.data_ptr() + 255) & ~255
+        L.check(self.lib.sgpo_guided_step_groups_mdlm(
+            self.n, self.members, self.row_lo, L.ptr(logits), L.ptr(x), Lq, K, self.S, float(t), int(mask_index), float(mt),
+            float(ms), float(guide_temp), self.seeds, self.offsets, row_offsets, L.ptr(slot_of_pos), L.ptr(self.lr),
+            self.lr_bytes, C.c_void_p(base), self.ws_bytes, L.ptr(x_out), L.ptr(nan_flag), L.stream_ptr()),
+            'sgpo_guided_step_groups_mdlm')
+        return x_out
+
+
 def reverse_step_udlm(logits, x, mt, ms, step_mode, noise_src=None, noise=None, want_probs=False):
     lib = L.load()
     B, Lq, K = logits.shape

@@ -421,3 +421,49 @@ def test_model_sampler_matrix_remaining_combinations(env):
     x = check(DAPS(mdlm, forward_op=pred, num_steps=3, ode_steps=4, mh_steps=100, alpha=4., beta=1., data_config=dc,
                    device='cuda:0'), mdlm)
     assert bool((x[:, [r - 1 for r in res1]] != ALPHABET.index('M')).any())
+
+
+@pytest.mark.parametrize('read_pos', [None, [3, 4, 9, 20, 21]])
+def test_guided_step_groups_entry_point_equals_one_call_per_group(env, read_pos):
+    """`sgpo_guided_step_groups_mdlm` through the C ABI: 19 stacked draws (more than one launch holds: 16), ragged
+    sizes, one of them unguided, each with its own value function and Philox key -- against
+    `sgpo_guidance_ratio_mlp_absorbing` + `sgpo_reverse_step_mdlm` called once per draw.  Bit-exact tokens, two steps
+    in a row (the second with the call offsets advanced)."""
+    from sgpo_amd import _lib as L
+    from sgpo_amd import weights as W
+    rt = env
+    Lq, K, S, mask = 23, 31, 31, 28
+    pos = list(range(Lq)) if read_pos is None else read_pos
+    sizes = [3, 1, 7, 2, 5, 4, 1, 6, 2, 3, 8, 1, 2, 5, 3, 4, 2, 9, 1]
+    gen = torch.Generator().manual_seed(12)
+    vfs = [None if i == 5 else rt.MlpValueFunction(W.mlp_synthetic_state(seed=70 + i, n_residues=len(pos)), pos)
+           for i in range(len(sizes))]
+    lo = [0]
+    for n in sizes:
+        lo.append(lo[-1] + n)
+    B = lo[-1]
+    slots = None
+    if read_pos is not None:
+        slots = torch.full((Lq,), -1, dtype=torch.int32)
+        for i, p in enumerate(pos):
+            slots[p] = i
+        slots = slots.cuda()
+    nan_a, nan_b = torch.zeros(1, dtype=torch.int32, device='cuda'), torch.zeros(1, dtype=torch.int32, device='cuda')
+    srcs_a = [rt.NoiseSource(seed=900 + i, row_offset=3 * i) for i in range(len(sizes))]
+    srcs_b = [rt.NoiseSource(seed=900 + i, row_offset=3 * i) for i in range(len(sizes))]
+    runner = rt.GuidedStepGroups([(vfs[i], srcs_a[i], lo[i], lo[i + 1]) for i in range(len(sizes))], S, 'cuda:0')
+    for step, (t, mt, ms) in enumerate([(40.0, 0.5, 0.45), (39.0, 0.45, 0.4)]):
+        logits = (torch.randn(B, Lq, K, generator=gen) * 2).cuda()
+        x = torch.randint(0, 28, (B, Lq), generator=gen)
+        x[torch.rand(B, Lq, generator=gen) < 0.5] = mask
+        x = x.cuda()
+        got = runner.step(logits, x, t, mt, ms, mask, 0.3, slots, nan_a, torch.empty_like(x))
+        want = torch.empty_like(x)
+        for i in range(len(sizes)):
+            xs = x[lo[i]:lo[i + 1]]
+            lr = vfs[i].jump_log_ratios(xs, t, S, mask_index=mask) if vfs[i] is not None else None
+            rt.reverse_step_mdlm(logits[lo[i]:lo[i + 1]], xs, mt, ms, mask, L.STEP_SOFT_CG, noise_src=srcs_b[i], log_ratio=lr,
+                                 slot_of_pos=slots if lr is not None else None, guide_temp=0.3, nan_flag=nan_b,
+                                 x_out=want[lo[i]:lo[i + 1]])
+        assert torch.equal(got, want), f'step {step}: {int((got != want).sum())} tokens differ'
+    assert int(nan_a.item()) == 0 and int(nan_b.item()) == 0
