@@ -329,6 +329,12 @@ class _Config1(_Config5):
         x = self.algo.inference(num_samples=self.B)
         return x, self.pred.log_likelihood(x)
 
+    def units(self):
+        return self.world * self.B        # (not the parent's: no stacked draws here)
+
+    def n_launches(self, steps):
+        return steps * (T_STEPS - 1) * 80 + 64
+
     def describe(self):
         return {'workload': 'MDLM prior sampling (cls_guidance_discrete at temperature 0) on CreiLOV, L=119, 127 reverse steps, '
                             '%d sequences per GPU and bench step' % self.B,

@@ -140,3 +140,22 @@ def test_sample_random_variants_draw_order(monkeypatch):
     ds.sample_random_variants(2)
     assert calls == [(4, 2, False), (20, None, True), (20, None, True)] * 2
     assert ds.get_full_sequence('WWWW') == 'MWGYWWPYGGWY'
+
+
+def test_bench_workloads_count_their_own_units():
+    """bench.py's `value` is units() * steps / time: every workload class states its own units per step (config 1 once
+    inherited config 5's ten stacked draws and reported ten times its rate)."""
+    import importlib.util
+    import os
+    spec = importlib.util.spec_from_file_location('bench_contract', os.path.join(os.path.dirname(os.path.dirname(__file__)), 'bench.py'))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    classes = [v for k, v in vars(bench).items() if isinstance(v, type) and k.startswith('_Config')]
+    assert len(classes) >= 4
+    for c in classes:
+        assert 'units' in c.__dict__ and 'describe' in c.__dict__, c.__name__
+
+    class _Fake:
+        world, B, DRAWS, steps_per_run = 2, 64, 10, 50
+    assert bench._Config1.units(_Fake) == 128
+    assert bench._Config5.units(_Fake) == 1280
