@@ -1071,7 +1071,9 @@ int launch_gemm_persistent(const GemmParams& p, int epi, const GemmSeg& sg, cons
   if (epi == EPI_QKV_ROPE && (p.head_dim != 64 || p.rope_cols % 64 != 0)) return SGPO_ERR_UNSUPPORTED;
   if (res && (p.xin == nullptr || (p.gate == nullptr && epi == EPI_GATE_RES))) return SGPO_ERR_UNSUPPORTED;
   // few tiles: the 64/128-row kernel of gemm.hip fills more CUs (one guided batch of 10 sequences is 1190 rows)
-  if (p.M < 1024 || ((p.M + 255) / 256) * ((p.N + 127) / 128) < gemm_cu_count() / 4) return SGPO_ERR_UNSUPPORTED;
+  static int pmin = -1;
+  if (pmin < 0) { const char* e = getenv("SGPO_GEMM_PMIN"); pmin = e ? atoi(e) : gemm_cu_count() / 4; }   // A/B: fewest 256x128 tiles for the persistent kernel
+  if (p.M < 1024 || ((p.M + 255) / 256) * ((p.N + 127) / 128) < pmin) return SGPO_ERR_UNSUPPORTED;
   if (p.N > 4096) return SGPO_ERR_UNSUPPORTED;   // bias table in LDS beside the ring; zero page (16 KiB) for a null bias
   if (p.K % 64 != 0 || sg.seg_k % 64 != 0) return SGPO_ERR_UNSUPPORTED;
   static int n_cu = 0, tile_mode = -1, dbg = 0;
