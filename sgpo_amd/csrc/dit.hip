@@ -191,6 +191,11 @@ const float* dit_ws_final_mod(const sgpo_dit* m, int B, int L, void* workspace) 
   return w.mod + (size_t)m->cfg.n_blocks * 6 * m->cfg.hidden;
 }
 
+// the fp32 residual stream after the last block (what hidden_out would receive), inside a forward workspace
+const float* dit_ws_hidden(const sgpo_dit* m, int B, int L, void* workspace) {
+  return dit_carve(m, B, L, (char*)workspace).x;
+}
+
 extern "C" size_t sgpo_dit_workspace_bytes(const sgpo_dit* m, int B, int L) {
   if (!m || B <= 0 || L <= 0) return 0;
   return dit_carve(m, B, L, nullptr).total;

@@ -21,6 +21,7 @@
 #include "prof.h"
 
 const float* dit_ws_final_mod(const sgpo_dit* m, int B, int L, void* workspace);
+const float* dit_ws_hidden(const sgpo_dit* m, int B, int L, void* workspace);
 
 #ifndef NOS_THREADS
 #define NOS_THREADS 768   // 12 waves share one copy of W in LDS: 3 per SIMD at <= 168 VGPRs
@@ -314,9 +315,10 @@ static size_t al256(size_t n) { return (n + 255) & ~(size_t)255; }
 
 extern "C" size_t sgpo_nos_workspace_bytes(const sgpo_dit* m, int B, int L) {
   if (!m || B <= 0 || L <= 0) return 0;
-  const size_t M = (size_t)B * L, H = m->cfg.hidden;
-  // h | logits[vocab] | the row-pair counters   (delta, G and p0 live in registers)
-  return al256(M * H * 4) + al256(M * m->cfg.vocab * 4) + NOS_QUEUES * 256;
+  const size_t M = (size_t)B * L;
+  // logits[vocab] | the row-pair counters   (the hidden state is read where the forward left it; delta, G and p0
+  // live in registers)
+  return al256(M * m->cfg.vocab * 4) + NOS_QUEUES * 256;
 }
 
 extern "C" int sgpo_nos_denoise(sgpo_dit* m, const int64_t* xt, const float* sigma, int n_sigma, int B, int L,
@@ -340,13 +342,13 @@ extern "C" int sgpo_nos_denoise(sgpo_dit* m, const int64_t* xt, const float* sig
   }
   const size_t M = (size_t)B * L, H = m->cfg.hidden, V = m->cfg.vocab;
   char* base = (char*)nos_workspace;
-  float* h = (float*)base; base += al256(M * H * 4);
   float* logits = (float*)base; base += al256(M * V * 4);
   int* next_pair = (int*)base;
   // 1. backbone once: hidden state + adaLN rows of the final layer (left in the DiT workspace)
   //    (hidden_in given: skip the blocks, only the conditioning + adaLN rows are computed)
-  int rc = sgpo_dit_forward(m, xt, sigma, n_sigma, B, L, hidden_in, logits, h, dit_workspace, dit_workspace_bytes, stream_);
+  int rc = sgpo_dit_forward(m, xt, sigma, n_sigma, B, L, hidden_in, logits, nullptr, dit_workspace, dit_workspace_bytes, stream_);
   if (rc) return rc;
+  const float* h = hidden_in ? hidden_in : dit_ws_hidden(m, B, L, dit_workspace);   // no copy: the kernel below runs before the workspace is used again
   const float* fmod = dit_ws_final_mod(m, B, L, dit_workspace);
   const int ns = sigma ? n_sigma : 1;
   NosArgs a;
