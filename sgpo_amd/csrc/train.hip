@@ -302,7 +302,17 @@ __global__ __launch_bounds__(256) void tr_mid(TrDev d, const float* __restrict__
   }
 }
 
-__global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L) {
+// torch.optim.Adam (single-tensor path): exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
+// value=1 - beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-step_size)
+__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gr, float lr_over_bc1, float bc2_sqrt,
+                                            float beta1, float beta2, float eps) {
+  m = m + (gr - m) * (1.0f - beta1);
+  v = v * beta2 + (1.0f - beta2) * gr * gr;
+  const float denom = sqrtf(v) / bc2_sqrt + eps;
+  p = p - lr_over_bc1 * (m / denom);
+}
+__global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restrict__ x, const float* __restrict__ t, int B, int L,
+                                               float lr_over_bc1, float bc2_sqrt, float beta1, float beta2, float eps) {
   __shared__ float in[TB][PAD], ws[H][PAD], dh[TB][PAD];   // 50 KB: three workgroups per CU
   __shared__ int toks[TB];
   const int c = (blockIdx.x + d.C - 1) % d.C, e = blockIdx.y, tid = threadIdx.x;   // the (heavier) time chunk, the last one, is dispatched first
@@ -333,8 +343,16 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
   // d mlp.0.weight[o][c*64 + k] = sum_b dh[b][o] in[b][k]   (rows >= B of both are zero)
   {
     const f32x16 acc = mfma64([&](int m, int k) { return dh[k][m]; }, [&](int k, int n) { return in[k][n]; }, 0.f);
-    float* gw = g + d.o_w0 + (size_t)c * H;
-    quad_store(acc, [&](int o, int k, float v) { gw[(size_t)o * d.D + k] = v; });
+    // Adam on this slice right here: mlp.0.weight is 96 % of the parameters, and its gradient would otherwise be
+    // written out and read back by tr_adam (8 of the 28 bytes per parameter that pass moves).  The slice was copied to
+    // LDS (ws) above, grad_in below reads that copy; no other workgroup touches this slice.
+    const size_t base = (size_t)e * d.P + d.o_w0 + (size_t)c * H;
+    quad_store(acc, [&](int o, int k, float gr) {
+      const size_t i = base + (size_t)o * d.D + k;
+      float pv = d.params[i], mv = d.m[i], vv = d.v[i];
+      adam_update(pv, mv, vv, gr, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+      d.m[i] = mv; d.v[i] = vv; d.params[i] = pv;
+    });
   }
   if (c < d.n_read) {
     __syncthreads();
@@ -380,73 +398,57 @@ __global__ __launch_bounds__(256) void tr_bwd0(TrDev d, const int64_t* __restric
   }
 }
 
-// gradient of parameter q of member e: the embedder's is the ordered sum of the per-position partials
-__device__ __forceinline__ float adam_grad(const TrDev& d, int e, int q, float stored) {
-  if (!(q >= d.o_ew && q < d.o_b0 && q < d.o_w0)) return stored;   // (callers only pass embedder parameters)
+// gradient of embedder parameter q of member e: the sum of the per-position partials in a fixed shape -- lane `part` of
+// the eight lanes that share the parameter adds positions part, part + 8, ... in order (all its loads in flight at
+// once), then the eight partial sums are combined by an xor tree.  (One thread per parameter walking all 119
+// positions was one memory latency per eight terms and set the duration of the whole pass.)
+__device__ __forceinline__ float adam_grad_emb(const TrDev& d, int e, int row, int k, int part) {
   const float* pe = d.part_e + (size_t)e * d.n_read * 32 * H;
-  int row, k;
-  if (q < d.o_eb) { k = (q - d.o_ew) / d.A; row = (q - d.o_ew) % d.A; }
-  else { k = q - d.o_eb; row = 31; }
   float gr = 0.f;
-  // loads eight positions ahead of the (ordered) adds: the chain is otherwise one memory latency per term
-  int c = 0;
-  for (; c + 8 <= d.n_read; c += 8) {
+  int c = part;
+  for (; c + 56 < d.n_read; c += 64) {
     float v8[8];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v8[u] = pe[((size_t)(c + u) * 32 + row) * H + k];
+    for (int u = 0; u < 8; ++u) v8[u] = pe[((size_t)(c + 8 * u) * 32 + row) * H + k];
 #pragma unroll
     for (int u = 0; u < 8; ++u) gr += v8[u];
   }
-  for (; c < d.n_read; ++c) gr += pe[((size_t)c * 32 + row) * H + k];
+  for (; c < d.n_read; c += 8) gr += pe[((size_t)c * 32 + row) * H + k];
+  gr += __shfl_xor(gr, 1);
+  gr += __shfl_xor(gr, 2);
+  gr += __shfl_xor(gr, 4);
   return gr;
 }
-// torch.optim.Adam (single-tensor path): exp_avg.lerp_(grad, 1 - beta1); exp_avg_sq.mul_(beta2).addcmul_(grad, grad,
-// value=1 - beta2); denom = (exp_avg_sq.sqrt() / bias_correction2_sqrt).add_(eps); param.addcdiv_(exp_avg, denom, value=-step_size)
-__device__ __forceinline__ void adam_update(float& p, float& m, float& v, float gr, float lr_over_bc1, float bc2_sqrt,
-                                            float beta1, float beta2, float eps) {
-  m = m + (gr - m) * (1.0f - beta1);
-  v = v * beta2 + (1.0f - beta2) * gr * gr;
-  const float denom = sqrtf(v) / bc2_sqrt + eps;
-  p = p - lr_over_bc1 * (m / denom);
-}
-// Four consecutive parameters of the flat [E][P] arrays per thread (16-byte loads and stores: the pass moves 28 bytes
-// per parameter and is bound by that); a quad may straddle two members.  The embedder's parameters, whose gradient is
-// a 119-term ordered sum, are left to the first `emb_blocks` blocks (dispatched first: they take longest), one thread
-// each (four of those chains in one thread made the whole pass wait for them).
+// Adam for everything except mlp.0.weight (96 % of the parameters: tr_bwd0 updates its slices where their gradient
+// is formed, so that gradient is never written out and read back).  The first `emb_blocks` blocks take the embedder,
+// whose gradient is a 119-term sum over the positions, eight lanes per parameter; the others one parameter per thread
+// over the index space with mlp.0.weight cut out.
 __global__ __launch_bounds__(256) void tr_adam(TrDev d, int emb_blocks, float lr_over_bc1, float bc2_sqrt, float beta1, float beta2, float eps) {
   const int emb_lo = d.o_ew, emb_hi = d.o_b0 < d.o_w0 ? d.o_b0 : d.o_w0;
   if ((int)blockIdx.x < emb_blocks) {
     const int n_emb = emb_hi - emb_lo;
-    const int j = (int)blockIdx.x * 256 + threadIdx.x;
-    if (j >= d.E * n_emb) return;
-    const int e = j / n_emb, q = emb_lo + j % n_emb;
+    const int j = ((int)blockIdx.x * 256 + threadIdx.x) >> 3, part = threadIdx.x & 7;   // eight lanes per parameter
+    if (j >= d.E * n_emb) return;       // (whole groups of eight leave together: 256 and the shuffles stay aligned)
+    // neighbouring lane groups take neighbouring hidden units k of one token row: their partials are neighbours in
+    // part_e ([position][row][k]), where walking the parameters in blob order ([k][token]) touched a line per lane
+    const int e = j / n_emb, j2 = j % n_emb;
+    const int row = j2 < H * d.A ? j2 / H : 31, k = j2 % H;
+    const int q = row < 31 ? d.o_ew + k * d.A + row : d.o_eb + k;
     const size_t i = (size_t)e * d.P + q;
-    adam_update(d.params[i], d.m[i], d.v[i], adam_grad(d, e, q, 0.f), lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
+    const float gr = adam_grad_emb(d, e, row, k, part);
+    if (part == 0) adam_update(d.params[i], d.m[i], d.v[i], gr, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
     return;
   }
-  const size_t n = (size_t)d.E * d.P;
-  const size_t i0 = ((blockIdx.x - emb_blocks) * (size_t)blockDim.x + threadIdx.x) * 4;
-  if (i0 >= n) return;
-  int q = (int)(i0 % d.P);
-  const bool plain = i0 + 4 <= n && q + 3 < d.P && q >= d.o_t1w && (q + 3 < emb_lo || q >= emb_hi);
-  if (plain) {   // all four trainable, of one member, none of them the embedder's
-    float4 p4 = *reinterpret_cast<const float4*>(d.params + i0), g4 = *reinterpret_cast<const float4*>(d.grads + i0);
-    float4 m4 = *reinterpret_cast<const float4*>(d.m + i0), v4 = *reinterpret_cast<const float4*>(d.v + i0);
-    adam_update(p4.x, m4.x, v4.x, g4.x, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
-    adam_update(p4.y, m4.y, v4.y, g4.y, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
-    adam_update(p4.z, m4.z, v4.z, g4.z, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
-    adam_update(p4.w, m4.w, v4.w, g4.w, lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
-    *reinterpret_cast<float4*>(d.m + i0) = m4;
-    *reinterpret_cast<float4*>(d.v + i0) = v4;
-    *reinterpret_cast<float4*>(d.params + i0) = p4;
-  } else {
-    for (size_t i = i0; i < n && i < i0 + 4; ++i) {
-      // (GaussianFourierProjection.W, q < o_t1w: requires_grad=False)
-      if (q >= d.o_t1w && !(q >= emb_lo && q < emb_hi))
-        adam_update(d.params[i], d.m[i], d.v[i], d.grads[i], lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
-      if (++q == d.P) q = 0;
-    }
-  }
+  const int w0_n = H * d.D, rest = d.P - w0_n;
+  const int r = ((int)blockIdx.x - emb_blocks) * 256 + threadIdx.x;
+  if (r >= d.E * rest) return;
+  const int e = r / rest;
+  int q = r % rest;
+  if (q >= d.o_w0) q += w0_n;
+  // (GaussianFourierProjection.W, q < o_t1w: requires_grad=False; the embedder: above)
+  if (q < d.o_t1w || (q >= emb_lo && q < emb_hi)) return;
+  const size_t i = (size_t)e * d.P + q;
+  adam_update(d.params[i], d.m[i], d.v[i], d.grads[i], lr_over_bc1, bc2_sqrt, beta1, beta2, eps);
 }
 
 }  // namespace
@@ -531,14 +533,14 @@ static int trainer_step(sgpo_mlp_trainer* t, const int64_t* x, const float* tt, 
   hipLaunchKernelGGL(tr_fwd0, dim3(n_groups, d.E), dim3(256), 0, s, d, x, tt, B, L);
   hipLaunchKernelGGL(tr_reduce, dim3((d.E * TB * H + 255) / 256), dim3(256), 0, s, d, B, n_groups);
   hipLaunchKernelGGL(tr_mid, dim3(d.E), dim3(256), t->mid_lds, s, d, y, B, n_groups, loss_out);
-  hipLaunchKernelGGL(tr_bwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L);
   t->step += 1;
   // torch/optim/adam.py _single_tensor_adam: the scalars are formed in double, applied to fp32 tensors
   const double bc1 = 1.0 - pow(beta1, (double)t->step), bc2 = 1.0 - pow(beta2, (double)t->step);
-  const size_t n = (size_t)d.E * d.P;
-  const int main_blocks = (int)((n + 1023) / 1024);
+  hipLaunchKernelGGL(tr_bwd0, dim3(d.C, d.E), dim3(256), 0, s, d, x, tt, B, L, (float)(lr / bc1), (float)sqrt(bc2),
+                     (float)beta1, (float)beta2, (float)eps);
+  const int main_blocks = (d.E * (d.P - H * d.D) + 255) / 256;
   const int n_emb = (d.o_b0 < d.o_w0 ? d.o_b0 : d.o_w0) - d.o_ew;
-  const int emb_blocks = (d.E * n_emb + 255) / 256;
+  const int emb_blocks = (d.E * n_emb * 8 + 255) / 256;   // eight lanes per embedder parameter
   hipLaunchKernelGGL(tr_adam, dim3((unsigned)(main_blocks + emb_blocks)), dim3(256), 0, s, d, emb_blocks,
                      (float)(lr / bc1), (float)sqrt(bc2), (float)beta1, (float)beta2, (float)eps);
   SGPO_CHECK_HIP(hipGetLastError());
