@@ -1,5 +1,5 @@
 // Row f-3: value-function ensemble training (training/train_classifier.py:7-64 -- Adam on the MSE of
-// MLPModel, problem/protein.py:58-121), all ensemble members in lockstep, five launches per optimiser step.
+// MLPModel, problem/protein.py:58-121), all ensemble members in lockstep, five launches per optimiser step (tr_adam: everything but mlp.0.weight, which tr_bwd0 updates).
 //   tr_fwd0   grid (chunk groups, members): two 64-wide input chunks (a residue's embedding each, or the time
 //             embedding) times their slices of mlp.0.weight, summed in the MFMA accumulators -> partial pre-activations
 //   tr_reduce grid over (member, row, unit): ordered sum of the partials + bias
