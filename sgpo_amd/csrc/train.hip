@@ -1,13 +1,14 @@
 // Row f-3: value-function ensemble training (training/train_classifier.py:7-64 -- Adam on the MSE of
-// MLPModel, problem/protein.py:58-121), all ensemble members in lockstep, five launches per optimiser step (tr_adam: everything but mlp.0.weight, which tr_bwd0 updates).
+// MLPModel, problem/protein.py:58-121), all ensemble members in lockstep, five launches per optimiser step.
 //   tr_fwd0   grid (chunk groups, members): two 64-wide input chunks (a residue's embedding each, or the time
 //             embedding) times their slices of mlp.0.weight, summed in the MFMA accumulators -> partial pre-activations
 //   tr_reduce grid over (member, row, unit): ordered sum of the partials + bias
 //   tr_mid    grid (members): the four 64x64 layers + head forward, MSE, and the
 //             backward pass down to d(pre-activation of mlp.0); activations live in LDS
-//   tr_bwd0   grid (chunks, members): gradient of the mlp.0.weight slice, of the chunk's input, and through the
-//             embedder (per-chunk partial sums per token) or the time embedder
-//   tr_adam   grid over all parameters: ordered sum of the embedder partials, torch.optim.Adam's update
+//   tr_bwd0   grid (chunks, members): gradient of the mlp.0.weight slice and Adam on it (96 % of the parameters: that
+//             gradient never leaves the chip), gradient of the chunk's input and through the embedder (per-chunk
+//             partial sums per token) or the time embedder
+//   tr_adam   grid over the other parameters: fixed-shape sum of the embedder partials, torch.optim.Adam's update
 // fp32 throughout (the 64x64x64 products on the matrix cores), every reduction in a fixed order (no atomics): a run
 // is reproducible bit for bit.
 #include "common.h"
