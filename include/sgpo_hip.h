@@ -107,6 +107,23 @@ int sgpo_reverse_step_udlm(const float* logits, const int64_t* x, int B, int L, 
                            const float* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
                            int64_t* x_out, float* probs_out, void* stream);
 
+/* UDLM under Classifier_Guidance_Inpaint.inference (sampling/cls_guidance.py:34-52 on a `diffusion: uniform` net,
+ * configs/model/udlm.yaml, scripts/run_prior_sample.sh:12): the posterior above, then -1 at the current token,
+ * the clamp/exp reweighting of get_guided_rates (models/mdlm.py:399-411), +1, clamp(min=0), normalise and
+ * torch.multinomial.  log_ratio [B][n_slots][K] holds every jump ratio (the uniform prior has no zero-rate
+ * columns); NULL or guide_temp 0 = unguided (prior_sample.py:69-76).  Arguments as sgpo_reverse_step_mdlm. */
+int sgpo_guided_step_udlm(const float* logits, const int64_t* x, const float* log_ratio, const int* slot_of_pos,
+                          int n_slots, int B, int L, int K, float move_chance_t, float move_chance_s,
+                          float guide_temp, int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                          uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag, void* stream);
+
+/* q_xt, uniform branch (mdlm_diffusion.py:593-601) under MDLM.q_sample (models/mdlm.py:104-109): each position
+ * is replaced w.p. move_chance[b] by a uniform token of [0, vocab).  noise_mode 2: noise [B][L] uniforms and
+ * noise_tokens [B][L] int64 (the reference's torch.rand and torch.randint draws). */
+int sgpo_q_sample_udlm(const int64_t* x, const float* move_chance, int B, int L, int vocab, int noise_mode,
+                       const float* noise, const int64_t* noise_tokens, uint64_t seed, uint64_t offset,
+                       uint64_t row_offset, int64_t* x_out, void* stream);
+
 /* MDLM.q_sample -> q_xt (models/mdlm.py:104-109, mdlm_diffusion.py:585-597): re-mask each
  * position w.p. move_chance[b].  noise: [B][L] uniforms for noise_mode 2. */
 int sgpo_q_sample_mdlm(const int64_t* x, const float* move_chance, int B, int L, int mask_index,

@@ -40,13 +40,15 @@ def project(x, mask, full_seq):
 
 
 def inference_mdlm(sd, B, L, T, mask_index, es, predictor=None, temperature=0.0, S=31,
-                   emulate_bf16=False, return_trace=False):
-    """MDLM + Classifier_Guidance_Inpaint.inference, T-1 steps; es[i] (B,L,S) Exp(1) draws."""
+                   emulate_bf16=False, return_trace=False, **model_kw):
+    """MDLM + Classifier_Guidance_Inpaint.inference, T-1 steps; es[i] (B,L,S) Exp(1) draws.
+    model_kw: diffusion / parameterization / time_conditioning of the net (configs/model/udlm.yaml for UDLM; the
+    start state is all-mask for every diffusion, models/mdlm.py:52-53)."""
     timesteps = torch.linspace(T - 1, 1, int((T - 1) / 1), dtype=int)
     x = mask_index * torch.ones((B, L), dtype=torch.int64)
     trace = []
     for i, t in enumerate(timesteps):
-        q = omdlm.p_sample(sd, x, t, T, mask_index, hard=False, emulate_bf16=emulate_bf16)
+        q = omdlm.p_sample(sd, x, t, T, mask_index, hard=False, emulate_bf16=emulate_bf16, **model_kw)
 
         def ratio_fn(qm):
             return omdlm.get_guided_rates(predictor, x, t, qm, S, guide_temp=temperature)[0]

@@ -38,6 +38,8 @@ SIGNATURES = {
     'sgpo_reverse_step_mdlm': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _vp, _u64, _u64,
                                     _u64, _vp, _vp, _vp, _vp]),
     'sgpo_reverse_step_udlm': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
+    'sgpo_guided_step_udlm': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
+    'sgpo_q_sample_udlm': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _u64, _u64, _u64, _vp, _vp]),
     'sgpo_q_sample_mdlm': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp]),
     'sgpo_categorical_sample': (_i, [_vp, _i64, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp]),
     'sgpo_mlp_create': (_i, [_vp, _sz, _i, C.POINTER(_i), _i, _i, _i, C.POINTER(_vp)]),

@@ -142,6 +142,74 @@ __global__ __launch_bounds__(256) void ln_gelu_kernel(const float* __restrict__ 
     *reinterpret_cast<uint2*>(out + (size_t)row * H + col) = pk;
   }
 }
+// H = 512 in the arithmetic of the fused GEMM epilogue (gemm_p.hip, EPI_LN_GELU), operation for operation, so that a
+// batch below the fused kernel's row threshold (GEMM + this pass) gives the bits of a batch above it: a rank's shard of
+// 32 sequences must reproduce the rows of the 64-sequence call.  The epilogue's order: the row is cut
+// into eight 64-column segments (its eight waves); in a segment, "lane half" h owns the quads at columns
+// 32 nt + 8 g + 4 h (nt < 2, g < 4): quad sums accumulated over (nt, g), the two halves added, / 64 -> mean_s; squared
+// deviations from mean_s as one fma chain over (nt, g, q), the halves added -> M2_s; the eight (mean_s, M2_s) combined
+// in segment order (Chan et al.); then fma(((v - mean) rstd), w, b), Abramowitz-Stegun GELU, bf16.
+// Here 16 lanes take a row (lane = 2 segment + half), four rows per wave.
+__global__ __launch_bounds__(256) void ln_gelu_row512_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ b, bf16_t* __restrict__ out, int M) {
+  const int lane = threadIdx.x & 63;
+  int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
+  const bool live = row < M;
+  if (!live) row = M - 1;                       // keep the shuffles whole; nothing is stored
+  const int seg = (lane & 15) >> 1, lh = lane & 1;
+  const float* xr = x + (size_t)row * 512 + seg * 64 + 4 * lh;
+  float4 v[2][4];
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) v[nt][g] = *reinterpret_cast<const float4*>(xr + nt * 32 + 8 * g);
+  float mean = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) mean = rn_add(mean, rn_add(rn_add(v[nt][g].x, v[nt][g].y), rn_add(v[nt][g].z, v[nt][g].w)));
+  mean = rn_mul(rn_add(mean, __shfl_xor(mean, 1)), 1.0f / 64.0f);
+  float sq = 0.f;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const float e[4] = {v[nt][g].x, v[nt][g].y, v[nt][g].z, v[nt][g].w};
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float d = e[q] - mean; sq = fmaf(d, d, sq); }
+    }
+  sq = rn_add(sq, __shfl_xor(sq, 1));
+  float ms = 0.f, m2 = 0.f, pm[8];
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) {
+    pm[s8] = __shfl(mean, (lane & 48) + 2 * s8);
+    ms = rn_add(ms, pm[s8]);
+    m2 = rn_add(m2, __shfl(sq, (lane & 48) + 2 * s8));
+  }
+  const float mu = rn_mul(ms, 0.125f);
+  float dv = 0.f;
+#pragma unroll
+  for (int s8 = 0; s8 < 8; ++s8) { const float d = pm[s8] - mu; dv = fmaf(d, d, dv); }
+  m2 = fmaf(64.0f, dv, m2);
+  const float rstd = rsqrtf(fmaf(m2, 1.0f / 512.0f, 1e-5f));
+  if (!live) return;
+#pragma unroll
+  for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int col = seg * 64 + nt * 32 + 8 * g + 4 * lh;
+      const float4 ww = *reinterpret_cast<const float4*>(w + col);
+      const float4 bb = *reinterpret_cast<const float4*>(b + col);
+      const float o0 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].x - mu, rstd), ww.x, bb.x));
+      const float o1 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].y - mu, rstd), ww.y, bb.y));
+      const float o2 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].z - mu, rstd), ww.z, bb.z));
+      const float o3 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].w - mu, rstd), ww.w, bb.w));
+      uint2 pk;
+      pk.x = pack_bf16x2(o0, o1);
+      pk.y = pack_bf16x2(o2, o3);
+      *reinterpret_cast<uint2*>(out + (size_t)row * 512 + col) = pk;
+    }
+}
 __global__ __launch_bounds__(256) void ln_gelu_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, bf16_t* __restrict__ out, int M,
                                                               int H) {
@@ -160,7 +228,7 @@ __global__ __launch_bounds__(256) void ln_gelu_generic_kernel(const float* __res
 static int launch_ln_gelu(const float* x, const float* w, const float* b, bf16_t* out, int M, int H, hipStream_t st) {
   dim3 grid((M + 3) / 4), block(256);
   ProfScope prof_scope(PK_LN_MOD, st, (double)M * H * 6.0);
-  if (H == 512) hipLaunchKernelGGL(ln_gelu_kernel<512>, grid, block, 0, st, x, w, b, out, M);
+  if (H == 512) hipLaunchKernelGGL(ln_gelu_row512_kernel, dim3((M + 15) / 16), block, 0, st, x, w, b, out, M);
   else if (H == 1024) hipLaunchKernelGGL(ln_gelu_kernel<1024>, grid, block, 0, st, x, w, b, out, M);
   else hipLaunchKernelGGL(ln_gelu_generic_kernel, grid, block, 0, st, x, w, b, out, M, H);
   SGPO_CHECK_HIP(hipGetLastError());

@@ -710,7 +710,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         for (int w = 0; w < 8; ++w) { const float d = pw[w].x - mu; dv = fmaf(d, d, dv); }
         m2 = fmaf(64.0f, dv, m2);
         mean[mt] = mu;
-        rstd[mt] = rsqrtf(m2 * (1.0f / (float)BN) + p.ln_eps);
+        rstd[mt] = rsqrtf(fmaf(m2, 1.0f / (float)BN, p.ln_eps));   // explicit: ln_gelu_row512_kernel (bytenet.hip) mirrors this
       }
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

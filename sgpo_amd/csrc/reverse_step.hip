@@ -258,11 +258,14 @@ int launch_reverse_step_mdlm_groups(const RsGroups& gs, int max_seq, const float
 }
 
 // ---------------------------------------------------------------------------
-// UDLM: log-softmax (d3pm parameterisation, no mask column) then _compute_posterior.
+// UDLM: log-softmax (d3pm parameterisation, no mask column) then _compute_posterior (models/mdlm.py:87-95).
+// SOFT_CG continues with the classifier-guidance algebra of sampling/cls_guidance.py:38-52 on the posterior -- the
+// uniform-diffusion prior is non-zero in every column, so log_ratio holds ALL jump ratios (no zero-rate skipping).
 __global__ __launch_bounds__(256) void reverse_step_udlm_kernel(
-    const float* __restrict__ logits, const int64_t* __restrict__ x, int rows, int K, float mt, float ms,
+    const float* __restrict__ logits, const int64_t* __restrict__ x, const float* __restrict__ log_ratio,
+    const int* __restrict__ slot_of_pos, int n_slots, int rows, int L, int K, float mt, float ms, float guide_temp,
     int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed, uint64_t offset,
-    uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out) {
+    uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out, int* __restrict__ nan_flag) {
   const int row = (blockIdx.x * 256 + threadIdx.x) >> 5;
   const int k = threadIdx.x & 31;
   if (row >= rows) return;
@@ -282,31 +285,83 @@ __global__ __launch_bounds__(256) void reverse_step_udlm_kernel(
   const float num = alpha_t * (float)K * px * oh + (alpha_ts - alpha_t) * oh + d_alpha * px +
                     (1.f - alpha_ts) * (1.f - alpha_s) * lim;
   const float den = alpha_t * (float)K * x_at_xt + (1.f - alpha_t);
-  const float q = act ? num / den : 0.f;
+  float q = act ? num / den : 0.f;
   const size_t lidx = (size_t)row * K + k;
-  if (probs_out && act) probs_out[lidx] = q;
-  if (step_mode == SGPO_STEP_SOFT) return;
   const uint64_t gidx = ((uint64_t)row + row_offset) * (uint64_t)K + k;
-  float dn = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, false) : 1.f;
-  float v = act ? q / dn : -INFINITY;
+  if (step_mode != SGPO_STEP_SOFT_CG) {
+    if (probs_out && act) probs_out[lidx] = q;
+    if (step_mode == SGPO_STEP_SOFT) return;
+    float dn = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, false) : 1.f;
+    float v = act ? q / dn : -INFINITY;
+    int samp = half_argmax(v, k);
+    if (k == 0) x_out[row] = samp;
+    return;
+  }
+  // classifier guidance (cls_guidance.py:38-52, models/mdlm.py:399-411), same operation order as the MDLM kernel
+  const bool guided = log_ratio != nullptr && guide_temp != 0.f;
+  if (k == xt) q -= 1.0f;
+  if (guided && act) {
+    const int l = row % L;
+    const int slot = slot_of_pos ? slot_of_pos[l] : l;
+    if (slot >= 0) {
+      float lr = log_ratio[((size_t)(row / L) * n_slots + slot) * K + k] / guide_temp;
+      if (lr == lr) lr = fminf(lr, 80.0f);  // torch.clamp propagates NaN
+      q = q * expf(lr);
+    }
+    if (nan_flag && q != q) atomicOr(nan_flag, 1);
+  }
+  if (k == xt) q += 1.0f;
+  q = q < 0.f ? 0.f : q;   // clamp(min=0) keeps a NaN
+  if (!act) q = 0.f;
+  const float tot = half_sum(q);
+  if (nan_flag && k == 0 && !(tot > 0.f && tot <= 3.4028234e38f)) atomicOr(nan_flag, 2);
+  const float p = q / tot;
+  if (probs_out && act) probs_out[lidx] = p;
+  float dn = act ? noise_denominator(noise_mode, noise, lidx, seed, offset, gidx, true) : 1.f;
+  float v = act ? p / dn : -INFINITY;
   int samp = half_argmax(v, k);
   if (k == 0) x_out[row] = samp;
+}
+
+static int launch_reverse_step_udlm(const float* logits, const int64_t* x, const float* log_ratio, const int* slot_of_pos,
+                                    int n_slots, int B, int L, int K, float move_chance_t, float move_chance_s,
+                                    float guide_temp, int step_mode, int noise_mode, const float* noise, uint64_t seed,
+                                    uint64_t offset, uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
+                                    void* stream) {
+  SGPO_REQUIRE(logits && x, "reverse_step_udlm: null logits/x");
+  SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_udlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
+  SGPO_REQUIRE(step_mode >= 0 && step_mode <= 2, "reverse_step_udlm: bad step_mode %d", step_mode);
+  SGPO_REQUIRE(noise_mode >= 0 && noise_mode <= 3, "reverse_step_udlm: bad noise_mode %d", noise_mode);
+  SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT ? probs_out != nullptr : x_out != nullptr, "reverse_step_udlm: output missing");
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise_mode == SGPO_NOISE_NONE || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_udlm: noise tensor missing");
+  SGPO_REQUIRE(log_ratio == nullptr || slot_of_pos != nullptr || n_slots == L, "reverse_step_udlm: n_slots must equal L without a slot map");
+  const int rows = B * L;
+  ProfScope prof_scope(PK_REVERSE_STEP, (hipStream_t)stream,
+                       (double)rows * (K * 4.0 * ((log_ratio && guide_temp != 0.f && step_mode == SGPO_STEP_SOFT_CG) ? 2 : 1) + 16.0));
+  hipLaunchKernelGGL(reverse_step_udlm_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, logits, x, log_ratio,
+                     slot_of_pos, n_slots, rows, L, K, move_chance_t, move_chance_s, guide_temp, step_mode, noise_mode, noise,
+                     seed, offset, row_offset, x_out, probs_out, nan_flag);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
 }
 
 extern "C" int sgpo_reverse_step_udlm(const float* logits, const int64_t* x, int B, int L, int K,
                                       float move_chance_t, float move_chance_s, int step_mode, int noise_mode,
                                       const float* noise, uint64_t seed, uint64_t offset, uint64_t row_offset,
                                       int64_t* x_out, float* probs_out, void* stream) {
-  SGPO_REQUIRE(logits && x, "reverse_step_udlm: null logits/x");
-  SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_udlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
   SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT || step_mode == SGPO_STEP_HARD, "reverse_step_udlm: step_mode must be SOFT or HARD");
-  SGPO_REQUIRE(step_mode == SGPO_STEP_SOFT ? probs_out != nullptr : x_out != nullptr, "reverse_step_udlm: output missing");
-  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || noise_mode == SGPO_NOISE_NONE || step_mode == SGPO_STEP_SOFT || noise, "reverse_step_udlm: noise tensor missing");
-  const int rows = B * L;
-  hipLaunchKernelGGL(reverse_step_udlm_kernel, dim3((rows + 7) / 8), dim3(256), 0, (hipStream_t)stream, logits, x, rows,
-                     K, move_chance_t, move_chance_s, step_mode, noise_mode, noise, seed, offset, row_offset, x_out, probs_out);
-  SGPO_CHECK_HIP(hipGetLastError());
-  return SGPO_OK;
+  return launch_reverse_step_udlm(logits, x, nullptr, nullptr, L, B, L, K, move_chance_t, move_chance_s, 0.f, step_mode,
+                                  noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nullptr, stream);
+}
+
+extern "C" int sgpo_guided_step_udlm(const float* logits, const int64_t* x, const float* log_ratio,
+                                     const int* slot_of_pos, int n_slots, int B, int L, int K, float move_chance_t,
+                                     float move_chance_s, float guide_temp, int noise_mode, const float* noise,
+                                     uint64_t seed, uint64_t offset, uint64_t row_offset, int64_t* x_out,
+                                     float* probs_out, int* nan_flag, void* stream) {
+  return launch_reverse_step_udlm(logits, x, log_ratio, slot_of_pos, n_slots, B, L, K, move_chance_t, move_chance_s,
+                                  guide_temp, SGPO_STEP_SOFT_CG, noise_mode, noise, seed, offset, row_offset, x_out,
+                                  probs_out, nan_flag, stream);
 }
 
 // ---------------------------------------------------------------------------
@@ -335,6 +390,42 @@ extern "C" int sgpo_q_sample_mdlm(const int64_t* x, const float* move_chance, in
   const int rows = B * L;
   hipLaunchKernelGGL(q_sample_mdlm_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, move_chance,
                      rows, L, mask_index, noise_mode, noise, seed, offset, row_offset, x_out);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
+// ---------------------------------------------------------------------------
+// q_xt, uniform branch (mdlm_diffusion.py:593-601): move = rand < move_chance; token = randint(0, vocab); where(move, token, x).
+__global__ __launch_bounds__(256) void q_sample_udlm_kernel(const int64_t* __restrict__ x, const float* __restrict__ mc,
+                                                            int rows, int L, int vocab, int noise_mode,
+                                                            const float* __restrict__ noise, const int64_t* __restrict__ noise_tokens,
+                                                            uint64_t seed, uint64_t offset, uint64_t row_offset,
+                                                            int64_t* __restrict__ x_out) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= rows) return;
+  float u;
+  int64_t tok;
+  if (noise_mode == SGPO_NOISE_PHILOX) {
+    Philox4 r = philox4x32_10(seed, (uint64_t)i + row_offset, offset);
+    u = (float)(r.x >> 8) * (1.0f / 16777216.0f);  // [0,1) like torch.rand
+    tok = (int64_t)(((uint64_t)r.y * (uint64_t)vocab) >> 32);  // uniform over [0, vocab)
+  } else {
+    u = noise[i];
+    tok = noise_tokens[i];
+  }
+  x_out[i] = (u < mc[i / L]) ? tok : x[i];
+}
+
+extern "C" int sgpo_q_sample_udlm(const int64_t* x, const float* move_chance, int B, int L, int vocab, int noise_mode,
+                                  const float* noise, const int64_t* noise_tokens, uint64_t seed, uint64_t offset,
+                                  uint64_t row_offset, int64_t* x_out, void* stream) {
+  SGPO_REQUIRE(x && move_chance && x_out, "q_sample_udlm: null argument");
+  SGPO_REQUIRE(B > 0 && L > 0 && vocab > 0, "q_sample_udlm: B=%d L=%d vocab=%d", B, L, vocab);
+  SGPO_REQUIRE(noise_mode == SGPO_NOISE_PHILOX || (noise_mode == SGPO_NOISE_UNIFORM && noise && noise_tokens),
+               "q_sample_udlm: noise_mode must be 0 or 2 (+ uniforms and tokens)");
+  const int rows = B * L;
+  hipLaunchKernelGGL(q_sample_udlm_kernel, dim3((rows + 255) / 256), dim3(256), 0, (hipStream_t)stream, x, move_chance,
+                     rows, L, vocab, noise_mode, noise, noise_tokens, seed, offset, row_offset, x_out);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }

@@ -201,12 +201,17 @@ class MDLM(GenerativeModel):
 
     def q_sample(self, x, t):
         """Forward noising (models/mdlm.py:104-109); t (B,) integer timesteps."""
-        if self.diffusion != 'absorbing_state':
-            raise NotImplementedError('q_sample: only absorbing-state diffusion is on the HIP path')
         sig, _ = self.model.noise(torch.as_tensor(t).to(torch.float32).cpu() / self.timestep)
         mc = 1 - torch.exp(-sig)
-        return rt.q_sample_mdlm(x.to(self._dev), mc, self.model.mask_index, noise_src=self.noise_source,
-                                noise=self._next_noise())
+        if self.diffusion == 'absorbing_state':
+            return rt.q_sample_mdlm(x.to(self._dev), mc, self.model.mask_index, noise_src=self.noise_source,
+                                    noise=self._next_noise())
+        if self.diffusion == 'uniform':     # mdlm_diffusion.py:598-601: torch.rand, then torch.randint(0, vocab)
+            u = self._next_noise()
+            tok = self.injected_noise.popleft() if u is not None else None
+            return rt.q_sample_udlm(x.to(self._dev), mc, self.model.vocab_size, noise_src=self.noise_source, noise=u,
+                                    noise_tokens=tok)
+        raise NotImplementedError(f'Diffusion type {self.diffusion} not implemented.')
 
     # ------------------------------------------------------------------ guidance
     def _jump_log_ratios(self, predictor_model, x, t, skip_zero_rate=False):
@@ -260,13 +265,23 @@ class MDLM(GenerativeModel):
         lr = slots = None
         if predictor_model is not None and guide_temp != 0:
             lr, slots = self._jump_log_ratios(predictor_model, x, t, skip_zero_rate=True)
-        xo, p = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_SOFT_CG,
-                                     noise_src=self.noise_source, noise=self._next_noise(), log_ratio=lr,
-                                     slot_of_pos=slots, guide_temp=guide_temp, want_probs=want_probs,
-                                     nan_flag=self._nan_flag)
+        xo, p = self._cg_reverse_step(logits, x, mt, ms, self.noise_source, self._next_noise(), lr, slots, guide_temp,
+                                      want_probs=want_probs)
         if check:
             self.check_nan()
         return (xo, p) if want_probs else xo
+
+    def _cg_reverse_step(self, logits, x, mt, ms, src, noise, lr, slots, guide_temp, want_probs=False, x_out=None):
+        """The reverse-step kernel of the net's diffusion in classifier-guidance mode: absorbing state (models/mdlm.py:78-86)
+        or the UDLM posterior (models/mdlm.py:87-95), then cls_guidance.py:38-52."""
+        if self.diffusion == 'absorbing_state':
+            return rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_SOFT_CG, noise_src=src, noise=noise,
+                                        log_ratio=lr, slot_of_pos=slots, guide_temp=guide_temp, want_probs=want_probs,
+                                        nan_flag=self._nan_flag, x_out=x_out)
+        if self.diffusion == 'uniform':
+            return rt.guided_step_udlm(logits, x, mt, ms, noise_src=src, noise=noise, log_ratio=lr, slot_of_pos=slots,
+                                       guide_temp=guide_temp, want_probs=want_probs, nan_flag=self._nan_flag, x_out=x_out)
+        raise NotImplementedError(f'Diffusion type {self.diffusion} not implemented.')
 
     @torch.no_grad()
     def guided_step_groups(self, x, t, groups, guide_temp):
@@ -288,9 +303,7 @@ class MDLM(GenerativeModel):
             lr = slots = None
             if pred is not None and guide_temp != 0:
                 lr, slots = self._jump_log_ratios(pred, xs, t, skip_zero_rate=True)
-            rt.reverse_step_mdlm(logits[lo:hi], xs, mt, ms, self.model.mask_index, L.STEP_SOFT_CG, noise_src=src,
-                                 log_ratio=lr, slot_of_pos=slots, guide_temp=guide_temp, nan_flag=self._nan_flag,
-                                 x_out=x_out[lo:hi])
+            self._cg_reverse_step(logits[lo:hi], xs, mt, ms, src, None, lr, slots, guide_temp, x_out=x_out[lo:hi])
         return x_out
 
     def _fused_groups(self, groups, Lq):

@@ -538,6 +538,54 @@ def reverse_step_udlm(logits, x, mt, ms, step_mode, noise_src=None, noise=None, 
     return x_out, probs
 
 
+def guided_step_udlm(logits, x, mt, ms, noise_src=None, noise=None, log_ratio=None, slot_of_pos=None, guide_temp=0.0,
+                     want_probs=False, nan_flag=None, x_out=None):
+    """sampling/cls_guidance.py:34-52 on a uniform-diffusion net: posterior -> CG reweight -> multinomial, one launch.
+    noise: injected Exp(1) draws (B, L, K) for parity runs."""
+    lib = L.load()
+    B, Lq, K = logits.shape
+    x = x.contiguous()
+    logits = logits.contiguous()
+    noise_mode = L.NOISE_PHILOX if noise is None else L.NOISE_EXPONENTIAL
+    if noise is not None:
+        assert noise.dtype == torch.float32
+        noise = noise.to(logits.device).contiguous()
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    probs = torch.empty_like(logits) if want_probs else None
+    if x_out is None:
+        x_out = torch.empty_like(x)
+    if log_ratio is not None:
+        log_ratio = log_ratio.contiguous()
+        assert log_ratio.dtype == torch.float32 and log_ratio.shape[0] == B and log_ratio.shape[2] == K
+    n_slots = Lq if log_ratio is None else log_ratio.shape[1]
+    L.check(lib.sgpo_guided_step_udlm(L.ptr(logits), L.ptr(x), L.ptr(log_ratio), L.ptr(slot_of_pos), n_slots, B, Lq, K,
+                                      float(mt), float(ms), float(guide_temp), noise_mode, L.ptr(noise), seed, off,
+                                      row_off * Lq, L.ptr(x_out), L.ptr(probs), L.ptr(nan_flag), L.stream_ptr()),
+            'sgpo_guided_step_udlm')
+    return x_out, probs
+
+
+def q_sample_udlm(x, move_chance, vocab, noise_src=None, noise=None, noise_tokens=None):
+    """q_xt's uniform branch (mdlm_diffusion.py:593-601); noise (B, L) uniforms + noise_tokens (B, L) int64 for parity runs."""
+    lib = L.load()
+    B, Lq = x.shape
+    x = x.contiguous()
+    move_chance = move_chance.to(x.device, torch.float32).reshape(-1).contiguous()
+    assert move_chance.numel() == B
+    noise_mode = L.NOISE_PHILOX if noise is None else L.NOISE_UNIFORM
+    if noise is not None:
+        assert noise_tokens is not None, 'q_sample_udlm: injected noise needs the uniform tokens too'
+        noise = noise.to(x.device, torch.float32).contiguous()
+        noise_tokens = noise_tokens.to(x.device, torch.int64).contiguous()
+        assert noise.shape == x.shape and noise_tokens.shape == x.shape
+    seed, off, row_off = (noise_src.seed, noise_src.next_offset(), noise_src.row_offset) if noise_src else (0, 0, 0)
+    out = torch.empty_like(x)
+    L.check(lib.sgpo_q_sample_udlm(L.ptr(x), L.ptr(move_chance), B, Lq, int(vocab), noise_mode, L.ptr(noise),
+                                   L.ptr(noise_tokens), seed, off, row_off * Lq, L.ptr(out), L.stream_ptr()),
+            'sgpo_q_sample_udlm')
+    return out
+
+
 def q_sample_mdlm(x, move_chance, mask_index, noise_src=None, noise=None):
     lib = L.load()
     B, Lq = x.shape

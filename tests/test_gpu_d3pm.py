@@ -13,6 +13,9 @@ from conftest import load_golden
 pytestmark = pytest.mark.gpu
 S = 26
 ALPHABET = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+# north_star's bf16 bound (1e-2) on denoiser outputs, relative to the range of the CPU restatement's values (ByteNet is
+# "parity unpinned": the restatement is the only oracle).  Observed: 3.6e-3 ... 8.6e-3.
+BN_TOL = 1e-2
 BN_DEV_SMALL = dict(n_tokens=31, d_embedding=8, d_model=128, n_layers=3, kernel_size=5)
 
 
@@ -111,12 +114,12 @@ def test_bytenet_forward_vs_oracle(rt, cfg, B, L):
         eh = (hid.cpu() - href).abs().max() / href.abs().max()
         el = (got.cpu() - ref).abs().max() / ref.abs().max()
         print(f'bytenet d_model={net.d_model} L={L} t={t}: hidden err {eh:.3e} logits err {el:.3e}')
-        assert eh < 2e-2 and el < 3e-2
+        assert eh < BN_TOL and el < BN_TOL
     # per-sequence timesteps
     tt = torch.tensor([3, 100, 499][:B])
     ref = obn.bytenet_forward(sd, x, tt)
     got = net.forward(x.cuda(), tt).cpu()
-    assert (got - ref).abs().max() / ref.abs().max() < 3e-2
+    assert (got - ref).abs().max() / ref.abs().max() < BN_TOL
 
 
 def test_bytenet_forward_large_batch_matches_small_batch(rt):
@@ -152,12 +155,28 @@ def test_bytenet_rows_do_not_depend_on_the_batch_size(rt):
         assert torch.equal(out[:1], first) and torch.equal(out[B - 1:B], last), B
 
 
+def _launch_counts(fn):
+    """{kernel kind: launches} of the library's own launch profiler (sgpo_prof_*) around fn()."""
+    import ctypes as C
+    from sgpo_amd import _lib as L
+    lib = L.load()
+    n = 64
+    L.check(lib.sgpo_prof_enable(1, 4096), 'prof_enable')
+    lib.sgpo_prof_reset()
+    out = fn()
+    torch.cuda.synchronize()
+    ms, cnt, work = (C.c_double * n)(), (C.c_int64 * n)(), (C.c_double * n)()
+    L.check(lib.sgpo_prof_read(n, ms, cnt, work), 'prof_read')
+    lib.sgpo_prof_enable(0, 0)
+    return out, {lib.sgpo_prof_kind_name(k).decode(): int(cnt[k]) for k in range(n) if cnt[k]}
+
+
 def test_bytenet_fused_layernorm_gemm_vs_two_pass_and_oracle(rt, monkeypatch):
     """M = 44 x 389 = 17116 rows (ragged last 128-row tile): the PFF1 and dilated-conv GEMMs take the full-row persistent
-    kernel whose epilogue does bias + LayerNorm + GELU (gemm_p.hip EPI_LN_GELU).  Checked against the CPU restatement to
-    the tolerance of the two-pass form, and against the two-pass form itself (SGPO_BYTENET_FUSED_LN=0): the two differ
-    only in the fp32 summation order of the row statistics, the erf approximation (1.5e-7) and hence in an occasional
-    bf16 rounding of an activation."""
+    kernel whose epilogue does bias + LayerNorm + GELU (gemm_p.hip EPI_LN_GELU).  Checked against the CPU restatement,
+    and against the two-pass form (SGPO_BYTENET_FUSED_LN=0: fp32-output GEMM + ln_gelu_row512_kernel), which since round 3
+    runs the epilogue's arithmetic operation for operation: the two must agree BIT FOR BIT (a shard
+    below the fused kernel's row threshold has to reproduce the rows of the unsharded batch)."""
     from oracle import bytenet as obn
     from sgpo_amd import weights as W
     sd = W.bytenet_synthetic_state(seed=5, n_layers=3)
@@ -166,22 +185,44 @@ def test_bytenet_fused_layernorm_gemm_vs_two_pass_and_oracle(rt, monkeypatch):
     B, L = 44, 389
     x = torch.randint(0, S, (B, L), generator=g)
     tt = torch.randint(1, 500, (B,), generator=g)
-    got, hid = net.forward(x.cuda(), tt.cuda(), return_hidden=True)
+    (got, hid), k_fused = _launch_counts(lambda: net.forward(x.cuda(), tt.cuda(), return_hidden=True))
     monkeypatch.setenv('SGPO_BYTENET_FUSED_LN', '0')
-    got2, hid2 = net.forward(x.cuda(), tt.cuda(), return_hidden=True)
+    (got2, hid2), k_pass = _launch_counts(lambda: net.forward(x.cuda(), tt.cuda(), return_hidden=True))
     monkeypatch.delenv('SGPO_BYTENET_FUSED_LN')
     again, _ = net.forward(x.cuda(), tt.cuda(), return_hidden=True)
     assert torch.equal(again, got)                                     # deterministic
-    assert not torch.equal(hid, hid2)                                  # the fused kernel really ran
-    d = (hid - hid2).abs().max() / hid2.abs().max()
-    print(f'fused vs two-pass: hidden {d:.3e} of the range, logits {(got - got2).abs().max() / got2.abs().max():.3e}')
-    assert d < 5e-3
+    fused_kind = 'gemm_bf16_kernel<EPI_LN_GELU>'
+    assert k_fused.get(fused_kind, 0) == 2 * 3 and fused_kind not in k_pass, (k_fused, k_pass)   # the fused kernel really ran
+    assert torch.equal(hid, hid2) and torch.equal(got, got2), \
+        f'fused vs two-pass: hidden {(hid - hid2).abs().max() / hid2.abs().max():.3e} of the range'
     ref, href = obn.bytenet_forward(sd, x[:6], tt[:6], return_hidden=True)
     eh = (hid[:6].cpu() - href).abs().max() / href.abs().max()
     el = (got[:6].cpu() - ref).abs().max() / ref.abs().max()
-    eh2 = (hid2[:6].cpu() - href).abs().max() / href.abs().max()
-    print(f'vs oracle: fused hidden {eh:.3e} logits {el:.3e}; two-pass hidden {eh2:.3e}')
-    assert eh < 2e-2 and el < 3e-2
+    print(f'vs oracle: hidden {eh:.3e} logits {el:.3e} of the range')
+    assert eh < BN_TOL and el < BN_TOL
+
+
+def test_bytenet_rows_do_not_depend_on_the_fused_kernel_threshold(rt):
+    """`gemm_ln_gelu` takes the fused EPI_LN_GELU kernel from (M + 127) / 128 >= n_cu / 2 tiles on
+    (about 43 sequences of 389 on 256 CUs) and the GEMM + pass below.  One sequence's logits across that switch
+    (B = 40 vs 44 vs 64) and a 64-sequence call against its two 32-sequence shards: bit-identical."""
+    from sgpo_amd import weights as W
+    sd = W.bytenet_synthetic_state(seed=5, n_layers=3)
+    net = rt.BytenetDenoiser(sd)
+    g = torch.Generator().manual_seed(9)
+    x = torch.randint(0, S, (64, 389), generator=g).cuda()
+    tt = torch.randint(1, 500, (64,), generator=g).cuda()
+    fused_kind = 'gemm_bf16_kernel<EPI_LN_GELU>'
+    whole, k64 = _launch_counts(lambda: net.forward(x, tt))
+    b40, k40 = _launch_counts(lambda: net.forward(x[:40].contiguous(), tt[:40].contiguous()))
+    b44, k44 = _launch_counts(lambda: net.forward(x[:44].contiguous(), tt[:44].contiguous()))
+    n_cu = torch.cuda.get_device_properties(0).multi_processor_count
+    if n_cu == 256:
+        assert fused_kind in k64 and fused_kind in k44 and fused_kind not in k40, (k40, k44, k64)
+    assert torch.equal(b40, whole[:40]) and torch.equal(b44, whole[:44])
+    lo = net.forward(x[:32].contiguous(), tt[:32].contiguous())
+    hi = net.forward(x[32:].contiguous(), tt[32:].contiguous())
+    assert torch.equal(torch.cat([lo, hi]), whole)
 
 
 def _mh_setup(rt, g):
@@ -282,20 +323,22 @@ def test_d3pm_dropin_and_daps_loop(rt):
     # teacher-forced p_sample against the oracle posterior on the oracle's fp32 logits
     gen = torch.Generator().manual_seed(4)
     x = torch.randint(0, S, (3, Lq), generator=gen)
+    from tf_common import TeacherForced
+    tf, i_step = TeacherForced(logit_rtol=2e-2, atol=1e-6), 0
     for t, tn in ((499, 472), (250, 237), (26, 0)):
         e = torch.empty(3, Lq, S, dtype=torch.float64).exponential_(1, generator=gen)
         logits = obn.bytenet_forward(sd, x, torch.tensor([t] * 3))
         p_ref = od3pm.p_sample(logits, x, t, tn, Q, Q_bar, sigma, S, hard=False)
         x_ref = od3pm.p_sample(logits, x, t, tn, Q, Q_bar, sigma, S, e=e.view(-1, S))
         p = net.p_sample(x.cuda(), torch.tensor(t), torch.tensor(tn), hard=False).cpu()
-        torch.testing.assert_close(p, p_ref, rtol=5e-2, atol=1e-4)     # bf16 denoiser
         net.injected_noise.append(e)
         xo = net.p_sample(x.cuda(), torch.tensor(t), torch.tensor(tn)).cpu()
-        v = p_ref / e
-        top2 = v.topk(2, dim=-1).values
-        ok = (top2[..., 0] - top2[..., 1]) > 1e-1 * top2[..., 0]
-        assert ok.float().mean() > 0.7
-        assert torch.equal(xo[ok], x_ref[ok])
+        # the bf16 bound is on LOGITS (1e-2 of the largest reference logit); the posterior takes p0 = softmax(z) SQUARED
+        # (defect D9, models/d3pm.py:255-257), so a logit error counts twice: logit_rtol 2e-2 in tf_common's bookkeeping,
+        # tokens compared wherever the race margin exceeds twice that, fraction printed and asserted by finish()
+        tf.step(i_step, p, p_ref, xo, x_ref.view(3, Lq), e, float(logits[..., :S].abs().max()))
+        i_step += 1
+    tf.finish('d3pm drop-in p_sample')
     # full DAPS loop through the drop-in API
     dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq=full, residues=res1)
     pred = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')

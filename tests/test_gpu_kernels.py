@@ -66,7 +66,9 @@ def test_dit_forward(rt, name):
     scale = g['logits'].abs().max()
     err = (logits - g['logits']).abs().max() / scale
     assert err < 1e-2, f'max err / max |logit| = {err:.3e}'      # north_star: bf16 rtol 1e-2
-    torch.testing.assert_close(hidden, g['h_last'], rtol=5e-2, atol=5e-2 * float(g['h_last'].abs().max()))
+    errh = (hidden - g['h_last']).abs().max() / g['h_last'].abs().max()
+    print(f'{name}: last hidden state, max err / max |h| = {errh:.3e}')
+    assert errh < 1e-2, f'hidden state: {errh:.3e}'                # the same bf16 bound on the residual stream
     # (b) the device error must be of the size the bf16 autocast rounding itself produces:
     #     compare with the oracle rounding to bf16 at the points torch autocast does (defect D7)
     ref16 = odit.dit_forward(sd, g['x'], g['sigma'], emulate_bf16=True)

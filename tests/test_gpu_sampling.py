@@ -385,9 +385,11 @@ def test_full_size_properties_config4(env):
 
 
 def test_model_sampler_matrix_remaining_combinations(env):
-    """The README matrix beyond the benchmarked pairs: UDLM (uniform diffusion, d3pm parameterisation, time-conditioned)
-    under the classifier-guided sampler (generic step: no fused kernel for it), and DAPS on an MDLM net.  No oracle trajectory exists for these pairs; each runs end to end and keeps the invariants of the
-    path: determinism under a seed, legal tokens, frozen positions equal to the parent."""
+    """The README matrix beyond the benchmarked pairs, end to end through the drop-in: UDLM (uniform diffusion, d3pm
+    parameterisation, time-conditioned) under the classifier-guided sampler on a residue subset -- its fused step is
+    `sgpo_guided_step_udlm`, and its PARITY is `test_cg_udlm_teacher_forced_against_reference_trajectory` below, this
+    test only adds the invariants of a whole run -- and DAPS on an MDLM net (no oracle trajectory exists for that
+    pair).  Each keeps determinism under a seed, legal tokens, frozen positions equal to the parent."""
     from models.mdlm import MDLM
     from problem.protein import ProteinPredictor
     from sampling.cls_guidance import Classifier_Guidance_Inpaint
@@ -421,6 +423,113 @@ def test_model_sampler_matrix_remaining_combinations(env):
     x = check(DAPS(mdlm, forward_op=pred, num_steps=3, ode_steps=4, mh_steps=100, alpha=4., beta=1., data_config=dc,
                    device='cuda:0'), mdlm)
     assert bool((x[:, [r - 1 for r in res1]] != ALPHABET.index('M')).any())
+
+
+UDLM_CFG = dict(diffusion='uniform', parameterization='d3pm', time_conditioning=True)    # configs/model/udlm.yaml:6-9
+
+
+def _build_udlm(g, T, Lq, full_seq, temp):
+    from models.mdlm import MDLM
+    from problem.protein import ProteinPredictor
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    from sgpo_amd import weights as W
+    dims = dict(zip(DIM_KEYS, [int(v) for v in g['dims']]))
+    sd = W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
+    cfg = dict(UDLM_CFG, model=dict(hidden_size=dims['hidden'], cond_dim=dims['cond_dim'], n_blocks=dims['n_blocks'],
+                                    n_heads=dims['n_heads'], length=1024))
+    net = MDLM('synthetic', cfg, None, num_steps=T, seq_len=Lq, device='cuda:0', state_dict=sd)
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq=full_seq, residues=None)
+    pred = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+    msd = W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=Lq)
+    pred.model.load_state_dict(msd)
+    pred.eval()
+    algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred if temp else None, temperature=temp, device='cuda:0')
+    return net, pred, algo, sd, msd
+
+
+@pytest.mark.parametrize('name,tag', [('cg_udlm_small', 'unguided'), ('cg_udlm_small', 'guided'),
+                                      ('cg_udlm_real', 'unguided'), ('cg_udlm_real', 'guided')])
+def test_cg_udlm_teacher_forced_against_reference_trajectory(env, name, tag):
+    """UDLM under Classifier_Guidance_Inpaint (scripts/run_prior_sample.sh:12: `model=udlm`; configs/model/udlm.yaml):
+    at every state of the REFERENCE's own run (goldens written by tools/refgen/make_goldens.py gen_cg_udlm) the device
+    step -- time-conditioned denoiser, sgpo_guidance_ratio_mlp (all jumps), sgpo_guided_step_udlm -- gives the oracle's
+    probabilities within the bf16 logit bound and the reference's next tokens wherever the race margin exceeds it.
+    Temperature 0 is the prior_sample.py path, > 0 the guided one; `real` = the real DiT dims on CreiLOV."""
+    from oracle import cls_guidance as ocg
+    from oracle import mdlm as omdlm
+    from oracle import mlp as omlp
+    g = load_golden(name)
+    T, temp = int(g['T']), float(g[f'temp_{tag}'])
+    B, Lq = g[f'x_{tag}'].shape
+    es = g[f'es_{tag}'] if f'es_{tag}' in g else golden_noise(g, B, Lq)
+    full_seq = bytes(g['full_seq'].numpy().tolist()).decode()
+    net, pred, algo, sd, msd = _build_udlm(g, T, Lq, full_seq, temp)
+    assert net.diffusion == 'uniform' and net.time_conditioning
+    opred = omlp.Predictor(msd)
+    states = g[f'states_{tag}'].long()
+    timesteps = torch.linspace(T - 1, 1, T - 1, dtype=int)
+    tf = TeacherForced()
+    for i, t in enumerate(timesteps):
+        xs = states[i]
+        e = es[i]
+        q, zmax = oracle_soft_step(sd, xs, t, T, diffusion='uniform')
+        x_ref, p_ref = ocg.cg_step(q, xs, lambda qm: omdlm.get_guided_rates(opred, xs, t, qm, 31, temp)[0], e)
+        want = states[i + 1] if i + 1 < T - 1 else g[f'x_{tag}']
+        assert torch.equal(x_ref, want), f'oracle left the reference trajectory at step {i}'
+        net.injected_noise.append(e)
+        xo, p = net.guided_step(xs.cuda(), t, algo.forward_op, algo.temperature, want_probs=True)
+        tf.step(i, p.cpu(), p_ref, xo.cpu(), x_ref, e, zmax)
+    tf.finish(f'{name}/{tag}')
+
+
+def test_cg_udlm_sampler_takes_the_uniform_step_and_q_sample(env):
+    """(a) `Classifier_Guidance_Inpaint.inference` on a UDLM net is the loop of the fused UDLM step: a free run under
+    Philox equals the same steps issued one by one through `guided_step`, and differs from what the absorbing-state
+    kernel would give on the same logits (the round-2 defect: a UDLM net silently took that kernel).  (b) `q_sample`
+    of a uniform net (q_xt's uniform branch, mdlm_diffusion.py:598-601; training/train_classifier.py:13 calls it)
+    reproduces the reference's result from the reference's two draws, and under Philox replaces a fraction
+    move_chance of the positions by tokens uniform over the 31 letters."""
+    from sgpo_amd import _lib as L
+    rt = env
+    g = load_golden('cg_udlm_small')
+    T = int(g['T'])
+    B, Lq = g['x_guided'].shape
+    full_seq = bytes(g['full_seq'].numpy().tolist()).decode()
+    net, pred, algo, sd, msd = _build_udlm(g, T, Lq, full_seq, 0.005)
+    net.reseed(5)
+    x_run = algo.inference(num_samples=64)
+    net.reseed(5)
+    x = net.get_start(64)
+    for t in torch.linspace(T - 1, 1, T - 1, dtype=int):
+        x = net.guided_step(x, t, pred, 0.005)
+    assert torch.equal(algo.project(x), x_run)
+    # the absorbing-state kernel on a UDLM state: different probabilities (carry-over one-hot vs posterior)
+    xs = g['states_guided'][5].long().cuda()
+    mt, ms, sig = net._move_chances(torch.tensor(9))
+    logits = net._denoise(xs, sig)
+    _, p_u = rt.guided_step_udlm(logits, xs, mt, ms, noise_src=rt.NoiseSource(1), want_probs=True)
+    _, p_a = rt.reverse_step_mdlm(logits, xs, mt, ms, 28, L.STEP_SOFT_CG, noise_src=rt.NoiseSource(1), want_probs=True)
+    assert float((p_u - p_a).abs().max()) > 0.1
+    # (b) q_sample, injected draws -> the reference's tokens
+    net.injected_noise.append(g['uq'])
+    net.injected_noise.append(g['tokq'])
+    xq = net.q_sample(g['xq'].cuda(), g['tq'])
+    assert torch.equal(xq.cpu(), g['xq_out'])
+    # Philox: rate and uniformity
+    n = 4096
+    x0 = torch.full((n, Lq), 3, dtype=torch.int64, device='cuda')
+    tq = torch.full((n,), 8)
+    xq = net.q_sample(x0, tq).cpu()
+    mc = 0.999 * 8 / T
+    hist = torch.bincount(xq.flatten(), minlength=31).double()
+    moved_to_other = 1.0 - float(hist[3]) / xq.numel()
+    assert abs(moved_to_other - mc * 30 / 31) < 0.01, (moved_to_other, mc)
+    others = torch.cat([hist[:3], hist[4:]])
+    assert float(others.min()) > 0.85 * float(others.mean()) and float(others.max()) < 1.15 * float(others.mean())
+    net.reseed(5)
+    a = net.q_sample(x0[:8], tq[:8])
+    net.reseed(5)
+    assert torch.equal(a, net.q_sample(x0[:8], tq[:8]))
 
 
 @pytest.mark.parametrize('read_pos', [None, [3, 4, 9, 20, 21]])

@@ -181,3 +181,46 @@ def test_taylor_guided_rates_against_reference():
     a, _ = omdlm.get_guided_rates(lin_onehot, xs, torch.tensor(9), q.clone(), 31, guide_temp=0.7, use_tag=True)
     b, _ = omdlm.get_guided_rates(lin_tokens, xs, torch.tensor(9), q.clone(), 31, guide_temp=0.7)
     torch.testing.assert_close(a, b, rtol=1e-4, atol=1e-8)
+
+
+UDLM_KW = dict(diffusion='uniform', parameterization='d3pm', time_conditioning=True)   # configs/model/udlm.yaml:6-9
+
+
+@pytest.mark.parametrize('name,tag', [('cg_udlm_small', 'unguided'), ('cg_udlm_small', 'guided'),
+                                      ('cg_udlm_real', 'unguided'), ('cg_udlm_real', 'guided')])
+def test_cls_guidance_inference_udlm(name, tag):
+    """UDLM under Classifier_Guidance_Inpaint.inference (scripts/run_prior_sample.sh:12; models/mdlm.py:87-95 +
+    mdlm_diffusion.py:392-419 inside sampling/cls_guidance.py:34-52): the restatement visits every state of the
+    reference's own run and reaches its final tokens, at temperature 0 (prior_sample.py) and > 0; small dims and the
+    real DiT dims on CreiLOV."""
+    g = load_golden(name)
+    sd = _sd(g)
+    T, temp = int(g['T']), float(g[f'temp_{tag}'])
+    B, L = g[f'x_{tag}'].shape
+    es = g[f'es_{tag}'] if f'es_{tag}' in g else golden_noise(g, B, L)
+    pred = omlp.Predictor(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=L)) if temp else None
+    x, trace = ocg.inference_mdlm(sd, B, L, T, 28, es, predictor=pred, temperature=temp, return_trace=True, **UDLM_KW)
+    states = g[f'states_{tag}'].long()
+    assert torch.equal(states[0], torch.full((B, L), 28))       # models/mdlm.py:52-53: all-mask start, also for UDLM
+    for i in range(1, T - 1):
+        assert torch.equal(trace[i - 1], states[i]), f'state before step {i}'
+    full = torch.tensor([ALPHABET.index(c) for c in bytes(g['full_seq'].numpy().tolist()).decode()])
+    assert torch.equal(ocg.project(x, torch.ones(L, dtype=torch.int64), full), g[f'x_{tag}'])
+    # a UDLM position keeps moving after it has left the mask (no carry-over): the absorbing-state step would not
+    moved = sum(int(((states[i] != 28) & (states[i + 1] != states[i])).sum()) for i in range(1, T - 2))
+    assert moved > 0
+
+
+def test_udlm_guided_rates_and_q_sample():
+    g = load_golden('cg_udlm_small')
+    sd = _sd(g)
+    T = int(g['T'])
+    L = g['xs'].shape[1]
+    pred = omlp.Predictor(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=L))
+    q = omdlm.p_sample(sd, g['xs'], 9, T, 28, hard=False, **UDLM_KW)
+    torch.testing.assert_close(q, g['q'], rtol=2e-4, atol=1e-7)
+    qg, _ = omdlm.get_guided_rates(pred, g['xs'], 9, q.clone(), 31, guide_temp=0.005)
+    torch.testing.assert_close(qg, g['qg'], rtol=2e-4, atol=1e-7)
+    assert float((g['qg'] / g['q']).max()) > 1.5      # the guidance is not a no-op at this temperature
+    xq = omdlm.q_sample(g['xq'], g['tq'], T, 28, g['uq'], diffusion='uniform', uniform_tokens=g['tokq'])
+    assert torch.equal(xq, g['xq_out'])

@@ -20,11 +20,18 @@ LOGIT_RTOL = 1e-2
 ATOL = 2e-6
 
 
-def oracle_soft_step(sd, xs, t, T, mask_index=28):
+def oracle_soft_step(sd, xs, t, T, mask_index=28, diffusion='absorbing_state'):
     """The oracle's soft reverse probabilities q at state xs (== omdlm.p_sample(..., hard=False)) together with
-    max |raw denoiser logit| of that state, the scale of the logit tolerance."""
+    max |raw denoiser logit| of that state, the scale of the logit tolerance.  diffusion 'uniform' = the UDLM net of
+    configs/model/udlm.yaml (d3pm parameterisation, time conditioned)."""
     from oracle import dit as odit
     from oracle import mdlm as omdlm
+    if diffusion == 'uniform':
+        _, _, sig_t = omdlm.move_chances(t, T, xs.shape[0])
+        z = odit.dit_forward(sd, xs, sig_t)
+        q = omdlm.p_sample(sd, xs, t, T, mask_index, diffusion='uniform', hard=False,
+                           log_p_x0=omdlm.d3pm_parameterization(z, mask_index))
+        return q, float(z.abs().max())
     z = odit.dit_forward(sd, xs, torch.zeros(xs.shape[0]))
     logp = omdlm.subs_parameterization(z, xs, mask_index)
     q = omdlm.p_sample(sd, xs, t, T, mask_index, hard=False, log_p_x0=logp)

@@ -356,6 +356,74 @@ def gen_cg_cfg1():
          full_seq=np.frombuffer(CREILOV.encode(), dtype=np.uint8))
 
 
+UDLM_CFG = dict(diffusion='uniform', parameterization='d3pm', time_conditioning=True)   # configs/model/udlm.yaml:6-9
+
+
+def gen_cg_udlm():
+    """UDLM under the samplers (scripts/run_prior_sample.sh:12, configs/model/udlm.yaml): the reference's own
+    Classifier_Guidance_Inpaint.inference on a `diffusion: uniform`, `parameterization: d3pm`, time-conditioned net --
+    models/mdlm.py:87-95 + mdlm_diffusion.py:392-419 inside sampling/cls_guidance.py:34-52 -- at temperature 0 (the
+    prior_sample.py:69-76 path) and > 0, with the state before every step.  `cg_udlm_small`: small DiT, noise stored;
+    `cg_udlm_real`: the real DiT dims, CreiLOV, a short horizon (T = 16), noise redrawn from its seed by the test.
+    Also MDLM.q_sample on the uniform net (q_xt's uniform branch, mdlm_diffusion.py:598-601) with its two draws."""
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, T = 2, 24, 16
+    full = CREILOV[:L]
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=full, residues=None))
+    pred, msd = build_ref_mlp(L, None, seed=43, full_len=L)
+    out = dict(seed=23, mlp_seed=43, dims=np.array(list(SMALL.values())), T=T,
+               full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
+    for tag, temp in (('unguided', 0.0), ('guided', 0.005)):   # synthetic value functions are flat: 0.005 gives ratios of e^+-1
+        net, core, sd = build_ref_mdlm(SMALL, seed=23, L=L, T=T, **UDLM_CFG)
+        algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred if temp else None, temperature=temp, device='cpu')
+        assert algo.temperature == temp
+        torch.manual_seed(81)
+        es = [torch.empty(B * L, 31).exponential_(1) for _ in range(T - 1)]
+        states = _record_states(net)
+        torch.manual_seed(81)
+        with torch.no_grad():
+            x = algo.inference(num_samples=B)
+        assert len(states) == T - 1
+        out.update({f'es_{tag}': torch.stack(es).view(T - 1, B, L, 31), f'x_{tag}': x, f'temp_{tag}': temp,
+                    f'states_{tag}': torch.stack(states).to(torch.int8)})
+    # one guided-rate evaluation at a fixed state for value-level parity + q_sample of the uniform net
+    net, core, sd = build_ref_mdlm(SMALL, seed=23, L=L, T=T, **UDLM_CFG)
+    g = torch.Generator().manual_seed(4)
+    xs = torch.randint(0, 31, (B, L), generator=g)
+    with torch.no_grad():
+        q = net.p_sample(xs, torch.tensor(9), hard=False)
+        qg = net.get_guided_rates(pred, xs, torch.tensor(9), q.clone(), guide_temp=0.005)
+    Bq = 5
+    xq = torch.randint(0, 26, (Bq, L), generator=g)
+    tq = torch.tensor([1, 5, 8, 12, 15])
+    torch.manual_seed(82)
+    uq = torch.rand(Bq, L)
+    tokq = torch.randint(0, 31, (Bq, L))
+    torch.manual_seed(82)
+    with torch.no_grad():
+        xq_out = net.q_sample(xq, tq)
+    assert bool((xq_out != xq).any())
+    save('cg_udlm_small', xs=xs, q=q, qg=qg, xq=xq, tq=tq, uq=uq, tokq=tokq, xq_out=xq_out, **out)
+
+    B, L, T, temp, noise_seed = 2, 119, 16, 0.064, 83
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=CREILOV, residues=None))
+    pred, msd = build_ref_mlp(L, None, seed=44, full_len=L)
+    out = dict(seed=24, mlp_seed=44, dims=np.array(list(REAL.values())), T=T, noise_seed=noise_seed,
+               full_seq=np.frombuffer(CREILOV.encode(), dtype=np.uint8))
+    for tag, tmp in (('unguided', 0.0), ('guided', temp)):
+        net, core, sd = build_ref_mdlm(REAL, seed=24, L=L, T=T, **UDLM_CFG)
+        algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred if tmp else None, temperature=tmp, device='cpu')
+        gen = torch.Generator().manual_seed(noise_seed)
+        es = torch.stack([torch.empty(B * L, 31).exponential_(1, generator=gen) for _ in range(T - 1)])
+        states = _record_states(net)
+        torch.manual_seed(noise_seed)
+        with torch.no_grad():
+            x = algo.inference(num_samples=B)
+        assert len(states) == T - 1
+        out.update({f'x_{tag}': x, f'temp_{tag}': tmp, f'states_{tag}': torch.stack(states).to(torch.int8)})
+    save('cg_udlm_real', es_isum=es.view(torch.int32).long().sum(), es_first=es[0, :4], **out)
+
+
 BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
 
 
@@ -916,7 +984,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
