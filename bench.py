@@ -408,6 +408,16 @@ def main_other(a):
     if world == 1 and a.gpus > 1:
         raise SystemExit('launch with torch.distributed.run --nproc-per-node N for --gpus N')
     dist, device, backend = _dist_init(world, local_rank)
+    line = run_other(a, dist, device, backend, rank, world)
+    if rank == 0:
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def run_other(a, dist, device, backend, rank, world):
+    """One of configs 1 / 3 / 4 / 5 (a.config) for a.warmup + a.steps steps in THIS process; the JSON line as a dict (rank 0)."""
     from sgpo_amd import _lib as L
     cls = {1: _Config1, 3: _Config3, 4: _Config4, 5: _Config5}[a.config]
     wl = cls(device, a.batch or cls.default_batch, rank, world)
@@ -487,18 +497,43 @@ def main_other(a):
             roof['note'] = ('kernel durations from a second pass over the same %d steps with per-kernel events on (%.1f ms per step '
                             'there): at this batch size the event records themselves are 40-60 %% of the wall clock, so the timed '
                             'region runs without them' % (a.steps, 1e3 * dt_prof / a.steps))
-    if rank == 0:
-        cpu = wl.cpu_baseline() if (not a.no_cpu_baseline and world == 1) else None
-        cfg = wl.describe()
-        cfg['baseline_config'] = a.config
-        print(json.dumps({
-            'metric': 'guided sequences/sec (whole node)', 'value': round(wl.units() * a.steps / dt, 3), 'unit': 'sequences/s',
-            'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
-            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'config': cfg,
-            'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'checksum': int(out[0].long().sum())}))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    cpu = wl.cpu_baseline() if (not a.no_cpu_baseline and world == 1) else None
+    cfg = wl.describe()
+    cfg['baseline_config'] = a.config
+    return {
+        'metric': 'guided sequences/sec (whole node)', 'value': round(wl.units() * a.steps / dt, 3), 'unit': 'sequences/s',
+        'n_gpus': world, 'steps': a.steps, 'warmup': a.warmup, 'ms_per_step': round(1e3 * dt / a.steps, 2),
+        'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'bf16', 'data': 'synthetic', 'config': cfg,
+        'roofline': roof, 'cpu_baseline': cpu, 'kernels': kernels, 'checksum': int(out[0].long().sum())}
+
+
+def config_legs(a, dist, device, backend, rank, world):
+    """After the headline region of the default run: short legs of BASELINE configs 1, 3, 4 and 5 in the same process
+    (the `_Config*` workloads of `--config N`, 2 timed steps after 1 warm-up each), so that the driver's one JSON line holds
+    a measured number for every configuration.  {'3': {value, unit, ms_per_step, kernel, frac, bound, cpu_baseline, ...}}."""
+    import copy
+    legs = {}
+    for cid in (1, 3, 4, 5):
+        b = copy.copy(a)
+        b.config, b.batch, b.steps, b.warmup = cid, None, 2, 1
+        try:
+            line = run_other(b, dist, device, backend, rank, world)
+        except Exception as exc:           # a leg must never take the headline line down with it
+            legs[str(cid)] = {'error': f'{type(exc).__name__}: {exc}'}
+            continue
+        torch.cuda.empty_cache()
+        if line is None:
+            continue
+        r = line['roofline'] or {}
+        legs[str(cid)] = {'value': line['value'], 'unit': line['unit'], 'ms_per_step': line['ms_per_step'], 'steps': b.steps,
+                          'warmup': b.warmup, 'workload': line['config']['workload'], 'kernel': r.get('kernel'),
+                          'bound': r.get('bound'), 'achieved': r.get('achieved'), 'roofline_unit': r.get('unit'),
+                          'frac': r.get('frac'), 'avg_launch_us': r.get('avg_launch_us'),
+                          'denoiser_tflops': r.get('denoiser_tflops'), 'gpu_busy_frac': r.get('gpu_busy_frac'),
+                          'cpu_baseline': line['cpu_baseline'], 'checksum': line['checksum']}
+    return legs
 
 
 def main():
@@ -510,6 +545,8 @@ def main():
     ap.add_argument('--batch', type=int, default=None, help='sequences per GPU per step (default: the configuration\'s)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-prof', action='store_true')
+    ap.add_argument('--no-skip-leg', action='store_true', help='skip the second (skip_unmasked) measurement')
+    ap.add_argument('--no-legs', action='store_true', help='default run only: skip the short legs of configs 1, 3, 4, 5')
     a = ap.parse_args()
     if a.config != 2:
         return main_other(a)
@@ -564,6 +601,32 @@ def main():
 
     roof = None
     kernels = {}
+    if not a.no_prof:
+        L.check(lib.sgpo_prof_enable(0, 0), 'prof_pause')       # stop recording, keep the records (read below)
+    # SECOND number, never the headline: the same steps with `skip_unmasked` -- sequences that hold no mask skip the
+    # denoiser forward of that step (output-identical, checked here by the token checksum of the same seeds).
+    skip = None
+    if not a.no_skip_leg:
+        k_skip = min(a.steps, 3)
+        want = [None] * k_skip
+        net.skip_unmasked = True
+        one_step(-1)
+        net.skipped_rows = net.denoised_rows = 0
+        sync()
+        t1 = time.perf_counter()
+        for i in range(k_skip):
+            want[i] = one_step(i)[0]
+        sync()
+        dts = time.perf_counter() - t1
+        if world > 1:
+            dts = _max_over_ranks(dist, backend, dts, device)
+        net.skip_unmasked = False
+        same = bool(torch.equal(want[k_skip - 1], out[0])) if k_skip == a.steps else None
+        skip = dict(value=round(world * B * k_skip / dts, 2), unit='sequences/s', steps=k_skip, ms_per_step=round(1e3 * dts / k_skip, 2),
+                    rows_skipped_frac=round(net.skipped_rows / max(net.skipped_rows + net.denoised_rows, 1), 4),
+                    tokens_identical_to_headline_run=same,
+                    note='opt-in MDLM(skip_unmasked=True): the denoiser runs only on sequences that still hold a mask; the '
+                         'headline `value` keeps the reference\'s one full forward per step')
     if not a.no_prof:
         n = L.PROF_KINDS
         ms = (C.c_double * n)()
@@ -732,8 +795,16 @@ def main():
                        'denoiser': 'DiT h512 x 8 blocks x 8 heads, cond 128, bf16 MFMA / fp32 accumulate',
                        'value_function': 'MLPModel hidden 64, fp32', 'global_batch': world * B,
                        'parallelism': f'dp{world} (independent shards + all-gather of tokens/scores)'},
+            'value_skip_unmasked': skip['value'] if skip else None, 'skip_unmasked': skip,
             'roofline': roof, 'cpu_baseline': cpu, 'fitness_ensemble': fit, 'acquisition': acq, 'ensemble_training': trn, 'kernels': kernels,
         }
+    legs = None
+    if world == 1 and not a.no_legs:         # N = 1 only, like cpu_baseline: the scaling runs time the headline alone
+        del algo, pred, net
+        torch.cuda.empty_cache()
+        legs = config_legs(a, dist, device, backend, rank, world)
+    if rank == 0:
+        line['configs'] = legs
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -86,7 +86,7 @@ def _load_dit_state(model_name, config):
 
 class MDLM(GenerativeModel):
     def __init__(self, model_name, config, tokenizer, num_steps=128, seq_len=389, device='cuda', state_dict=None,
-                 t_next_mode='reference'):
+                 t_next_mode='reference', skip_unmasked=False):
         self.tokenizer = _instantiate_tokenizer(tokenizer)
         dev = rt.init(device if str(device) != 'cuda' else None)
         sd = state_dict if state_dict is not None else _load_dit_state(model_name, config)
@@ -102,6 +102,13 @@ class MDLM(GenerativeModel):
         self.parameterization = cfg_get(config, 'parameterization', 'subs')
         self.time_conditioning = bool(cfg_get(config, 'time_conditioning', False))
         self.t_next_mode = t_next_mode
+        # Opt-in, output-identical: in the classifier-guidance step a sequence WITHOUT a masked position does not need the
+        # denoiser (at an unmasked position the subs parameterisation replaces the logits by the carry-over one-hot,
+        # mdlm_diffusion.py:338-340, so the step reads only the token, the schedule, the jump ratio and the noise).  With
+        # defect D2 about (127/128)^L of the sequences are in that state at any step after the first (39 % at L = 119).
+        # False (default) keeps the reference's one full forward per step.
+        self.skip_unmasked = bool(skip_unmasked)
+        self.skipped_rows = self.denoised_rows = 0
         self.global_batch = None        # set by a sharded caller: the unsharded batch size (NOS batchmean KL)
         self.noise_source = rt.NoiseSource(seed=torch.initial_seed())
         self.injected_noise = deque()   # parity runs: tensors consumed by successive sampling calls
@@ -135,6 +142,28 @@ class MDLM(GenerativeModel):
         if self.time_conditioning and sigma_t is not None:
             sig = torch.as_tensor(sigma_t, dtype=torch.float32).reshape(-1)[:1].to(self._dev)
         return self.net.forward(x, sig, out=out)
+
+    def _denoise_for_cg(self, x, sigma_t):
+        """Logits for the classifier-guidance step.  skip_unmasked: the denoiser runs on the sequences that still hold a
+        mask only (one device-to-host read of their count per step); the other rows of the returned buffer keep whatever
+        they held -- the reverse-step kernel never uses them (reverse_step.hip: `lp` is overwritten where x != mask).  A
+        row's logits do not depend on the batch it is in (tests: batch-size invariance), so the tokens are those of the
+        full forward bit for bit."""
+        if not (self.skip_unmasked and self.diffusion == 'absorbing_state'):
+            return self._denoise(x, sigma_t)
+        B = x.shape[0]
+        idx = (x == self.model.mask_index).any(dim=1).nonzero().squeeze(1)
+        n = int(idx.numel())
+        self.denoised_rows += n
+        self.skipped_rows += B - n
+        buf = self.__dict__.get('_cg_logits')
+        if buf is None or buf.shape[0] != B or buf.shape[1] != x.shape[1]:
+            buf = self._cg_logits = torch.zeros(B, x.shape[1], self.S, dtype=torch.float32, device=self._dev)
+        if n == B:
+            return self._denoise(x, sigma_t, out=buf)
+        if n > 0:
+            buf.index_copy_(0, idx, self._denoise(x.index_select(0, idx), sigma_t))
+        return buf
 
     # ------------------------------------------------------------------ reference API
     def sample(self, num_samples):
@@ -261,7 +290,7 @@ class MDLM(GenerativeModel):
         a NaN rate or a row it cannot sample from (one device-to-host read).  The sampling loop passes False and calls
         `check_nan()` every few steps instead."""
         mt, ms, sig_t = self._move_chances(t)
-        logits = self._denoise(x, sig_t)
+        logits = self._denoise_for_cg(x, sig_t)
         lr = slots = None
         if predictor_model is not None and guide_temp != 0:
             lr, slots = self._jump_log_ratios(predictor_model, x, t, skip_zero_rate=True)
@@ -291,7 +320,7 @@ class MDLM(GenerativeModel):
         [lo, hi) of x.  A row's logits do not depend on the batch it is in (tests: batch-size invariance), so every group
         gets exactly the tokens its own `guided_step` call would have produced."""
         mt, ms, sig_t = self._move_chances(t)
-        logits = self._denoise(x, sig_t)
+        logits = self._denoise_for_cg(x, sig_t)
         x_out = torch.empty_like(x)
         fused = self._fused_groups(groups, x.shape[1]) if self.diffusion == 'absorbing_state' else None
         if fused is not None:      # every group's value function lives in the library: one call steps them all
