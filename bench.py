@@ -220,7 +220,7 @@ class _Config4:
     def step(self, i):
         from sgpo_amd.dist import run_cells
         cells = [(self.COEFS[(i * self.world + r) % len(self.COEFS)], (i * self.world + r) // len(self.COEFS)) for r in range(self.world)]
-        out = run_cells(cells, self._cell, seed=42 + i, rank=self.rank, world=self.world)
+        out = run_cells(cells, self._cell, seed=42 + i, rank=self.rank, world=self.world, rows_per_cell=self.B)
         return out[0][0], None
 
     def units(self):
@@ -293,7 +293,7 @@ class _Config5(_Config4):
         got = []
         thompson_round(self._draw, lambda t, s: (got.append((t, s)) or t.shape[0]), n_needed=10 ** 9,
                        max_draws=self.world * self.DRAWS, pick_member=lambda: int(self.rng.randint(0, 10)), seed=1000 + i,
-                       rank=self.rank, world=self.world, per_rank=self.DRAWS, draw_many=self._draw_many)
+                       rank=self.rank, world=self.world, per_rank=self.DRAWS, draw_many=self._draw_many, rows_per_draw=self.B)
         return torch.cat([t for t, _ in got]), torch.cat([s for _, s in got])
 
     def units(self):
@@ -382,17 +382,6 @@ def _dist_init(world, local_rank):
     return dist, device, backend
 
 
-def _all_gather(dist, backend, out, x):
-    x = x.detach()
-    if backend == 'nccl':
-        dist.all_gather_into_tensor(out, x)
-    else:
-        host = torch.empty(out.shape, dtype=out.dtype)
-        with torch.no_grad():
-            dist.all_gather_into_tensor(host, x.cpu())
-        out.copy_(host)
-
-
 def _max_over_ranks(dist, backend, dt, device):
     tt = torch.tensor([dt], dtype=torch.float64, device=device if backend == 'nccl' else 'cpu')
     dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -425,13 +414,9 @@ def run_other(a, dist, device, backend, rank, world):
 
     def one_step(i):
         x, sc = wl.step(i)
-        if world > 1 and a.config in (1, 3):     # batch rows sharded: the all-gather of tokens (uint8) and scores
-            B = x.shape[0]
-            all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
-            all_s = torch.empty(world * B, dtype=torch.float32, device=device)
-            _all_gather(dist, backend, all_t, x.to(torch.uint8))
-            _all_gather(dist, backend, all_s, sc.to(torch.float32))
-            return all_t, all_s
+        if world > 1 and a.config in (1, 3):     # batch rows sharded: ONE all-gather of tokens (uint8) + scores
+            from sgpo_amd.dist import gather_samples
+            return gather_samples(x, sc.to(torch.float32), max_rows=x.shape[0])
         return x, sc
 
     def sync():
@@ -570,13 +555,9 @@ def main():
         net.reseed(seed=42 + step_idx, row_offset=rank * B)
         x = algo.inference(num_samples=B)
         score = pred.log_likelihood(x)
-        if world > 1:
-            toks = x.to(torch.uint8)
-            all_t = torch.empty(world * B, x.shape[1], dtype=torch.uint8, device=device)
-            all_s = torch.empty(world * B, dtype=torch.float32, device=device)
-            _all_gather(dist, backend, all_t, toks)
-            _all_gather(dist, backend, all_s, score)
-            return all_t, all_s
+        if world > 1:      # ONE all-gather of tokens (uint8) + scores per batch (sgpo_amd.dist.gather_rows)
+            from sgpo_amd.dist import gather_samples
+            return gather_samples(x, score, max_rows=B)
         return x, score
 
     def sync():

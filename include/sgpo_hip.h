@@ -58,7 +58,11 @@ typedef struct {
 } sgpo_dit_config;
 
 /* ---- library ------------------------------------------------------------ */
-int sgpo_init(int device);            /* binds the calling process to `device`, one rank per GPU */
+/* Binds the calling process to `device`.  ONE DEVICE PER PROCESS (one rank per GPU, as torch.distributed.run starts
+ * them): launch settings that depend on the device (CU count, tile rule, dynamic-LDS attributes) are cached per
+ * process, so a later sgpo_init with another device index fails with SGPO_ERR_ARG instead of running with the first
+ * device's settings.  Calling it again with the same index is harmless. */
+int sgpo_init(int device);
 const char* sgpo_last_error(void);    /* thread-local message of the last failing call */
 int sgpo_version(void);
 

@@ -23,10 +23,18 @@ extern "C" int sgpo_version(void) { return 1; }
 extern "C" int sgpo_gemm_init_device();
 extern "C" int sgpo_guidance_init_device();
 
+// One device per process (one rank per GPU): the per-process caches of the launchers -- CU count and tile rule
+// (gemm_p.hip), dynamic-LDS attributes (dit_kernels.hip, nos.hip) -- are taken on the device bound here, so a second
+// device in the same process is refused instead of silently running with the first one's settings.
+static int g_bound_device = -1;
 extern "C" int sgpo_init(int device) {
   int n = 0;
   SGPO_CHECK_HIP(hipGetDeviceCount(&n));
   SGPO_REQUIRE(device >= 0 && device < n, "sgpo_init: device %d not in [0,%d)", device, n);
+  SGPO_REQUIRE(g_bound_device < 0 || g_bound_device == device,
+               "sgpo_init: this process is bound to device %d; the library supports one device per process (start one "
+               "process per GPU)", g_bound_device);
+  g_bound_device = device;
   SGPO_CHECK_HIP(hipSetDevice(device));
   if (int rc = sgpo_gemm_init_device()) return rc;
   return sgpo_guidance_init_device();   // device address of the allocation-free entry point's scratch array

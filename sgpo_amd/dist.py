@@ -41,39 +41,76 @@ def shard_bounds(n_rows, rank, world):
     return lo, lo + base + (1 if rank < rem else 0)
 
 
+def _wire(group):
+    """Device the collective runs on: gloo carries host tensors only (a rehearsal of the N > 1 flow with GPU tensors
+    stages the exchange through the host), RCCL takes the GPU tensors where they are."""
+    return torch.device('cpu') if dist.get_backend(group) == 'gloo' else None
+
+
 @torch.no_grad()
-def gather_samples(tokens, scores=None, group=None):
-    """All-gather per-rank samples.  tokens (b_r, L) integer -> (sum b_r, L) uint8 on every rank
-    (tokens < 256: the 31-letter alphabet), scores (b_r,) fp32 -> (sum b_r,).  Ranks may hold
-    different row counts (ragged shards are padded to the maximum and trimmed)."""
-    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
-        return tokens.to(torch.uint8), scores
-    world = dist.get_world_size(group)
-    home = tokens.device
-    # gloo carries host tensors only: a rehearsal of the N > 1 flow with GPU tensors stages the exchange through the host
-    dev = torch.device('cpu') if dist.get_backend(group) == 'gloo' else home
-    tokens = tokens.detach().to(dev)
-    scores = scores if scores is None else scores.detach().to(dev)
-    n = torch.tensor([tokens.shape[0]], dtype=torch.int64, device=dev)
-    counts = [torch.zeros_like(n) for _ in range(world)]
-    dist.all_gather(counts, n, group=group)
-    counts = [int(c.item()) for c in counts]
-    mx = max(counts)
-    Lq = tokens.shape[1]
-    pad_t = torch.zeros(mx, Lq, dtype=torch.uint8, device=dev)
-    pad_t[:tokens.shape[0]] = tokens.to(torch.uint8)
-    all_t = torch.empty(world * mx, Lq, dtype=torch.uint8, device=dev)
-    dist.all_gather_into_tensor(all_t, pad_t, group=group)
-    keep = torch.cat([torch.arange(r * mx, r * mx + c, device=dev) for r, c in enumerate(counts)])
-    out_t = all_t[keep].to(home)
-    out_s = None
-    if scores is not None:
-        pad_s = torch.zeros(mx, dtype=torch.float32, device=dev)
-        pad_s[:scores.shape[0]] = scores.to(torch.float32)
-        all_s = torch.empty(world * mx, dtype=torch.float32, device=dev)
-        dist.all_gather_into_tensor(all_s, pad_s, group=group)
-        out_s = all_s[keep].to(home)
-    return out_t, out_s
+def gather_rows(tokens, scores=None, tags=None, max_rows=None, group=None):
+    """ONE all-gather of per-rank sample rows: every row travels as L token bytes + 4 score
+    bytes + 8 tag bytes in one padded uint8 matrix, the rank's row count in a 16-byte header in front of it.
+
+    tokens (b_r, L) integer (< 256: the 31-letter alphabet), scores (b_r,) fp32 or None, tags (b_r,) int64 or None.
+    max_rows: an upper bound of b_r that every rank knows without asking (a shard size, draws x batch): with it the
+    exchange is exactly one collective.  Without it the ranks first exchange (b_r, L) -- a second, 16-byte
+    collective -- which is also how a rank that produced nothing learns the row width (tokens may then be None).
+    Returns (tokens uint8 (sum b_r, L), scores or None, tags or None) in rank order on every rank."""
+    on = dist.is_available() and dist.is_initialized()
+    world = dist.get_world_size(group) if on else 1
+    if world == 1:
+        return tokens.to(torch.uint8), scores, tags
+    home = tokens.device if tokens is not None else None
+    dev = _wire(group) or home
+    n = 0 if tokens is None else int(tokens.shape[0])
+    Lq = 0 if tokens is None else int(tokens.shape[1])
+    if max_rows is None or tokens is None:
+        mine = torch.tensor([n, Lq], dtype=torch.int64, device=dev or 'cpu')
+        sizes = torch.empty(world * 2, dtype=torch.int64, device=mine.device)
+        dist.all_gather_into_tensor(sizes, mine, group=group)
+        sizes = sizes.view(world, 2).cpu()
+        Lq = int(sizes[:, 1].max())
+        max_rows = max(int(sizes[:, 0].max()), 1 if max_rows is None else max_rows)
+        if tokens is None:
+            home = home or mine.device
+            dev = dev or home
+            tokens = torch.empty(0, Lq, dtype=torch.uint8, device=dev)
+    assert n <= max_rows, f'gather_rows: {n} rows exceed max_rows {max_rows}'
+    width = Lq + 12
+    buf = torch.zeros(16 + max_rows * width, dtype=torch.uint8, device=dev)
+    flags = (1 if scores is not None else 0) | (2 if tags is not None else 0)
+    buf[:16] = torch.tensor([n, flags], dtype=torch.int64).view(torch.uint8).to(dev)
+    body = buf[16:].view(max_rows, width)
+    if n:
+        body[:n, :Lq] = tokens.detach().to(dev).to(torch.uint8)
+        if scores is not None:
+            body[:n, Lq:Lq + 4] = scores.detach().to(dev, torch.float32).contiguous().view(torch.uint8).view(n, 4)
+        if tags is not None:
+            body[:n, Lq + 4:] = tags.detach().to(dev, torch.int64).contiguous().view(torch.uint8).view(n, 8)
+    out = torch.empty(world * buf.numel(), dtype=torch.uint8, device=dev)
+    dist.all_gather_into_tensor(out, buf, group=group)
+    out = out.view(world, buf.numel())
+    head = out[:, :16].flatten().clone().view(torch.int64).view(world, 2).cpu()          # (world, 2): count, flags -- one small read
+    counts = [int(c) for c in head[:, 0]]
+    any_flags = 0
+    for c, f in zip(counts, head[:, 1].tolist()):
+        if c:
+            any_flags |= int(f)
+    bodies = out[:, 16:].view(world, max_rows, width)
+    rows = torch.cat([bodies[r, :c] for r, c in enumerate(counts)]) if sum(counts) else bodies[0, :0]
+    nrow = rows.shape[0]
+    out_t = rows[:, :Lq].contiguous().to(home)
+    out_s = rows[:, Lq:Lq + 4].flatten().clone().view(torch.float32).view(nrow).to(home) if any_flags & 1 else None
+    out_g = rows[:, Lq + 4:].flatten().clone().view(torch.int64).view(nrow).to(home) if any_flags & 2 else None
+    return out_t, out_s, out_g
+
+
+def gather_samples(tokens, scores=None, group=None, max_rows=None):
+    """All-gather per-rank samples: tokens (b_r, L) integer -> (sum b_r, L) uint8 on every rank, scores (b_r,) fp32 ->
+    (sum b_r,).  Ranks may hold different row counts.  One collective when `max_rows` is given (`gather_rows`)."""
+    t, s, _ = gather_rows(tokens, scores, None, max_rows=max_rows, group=group)
+    return t, s
 
 
 def sharded_inference(algo, num_samples, seed, rank=None, world=None, score_fn=None, **kw):
@@ -100,7 +137,7 @@ def sharded_inference(algo, num_samples, seed, rank=None, world=None, score_fn=N
     s = None
     if score_fn is not None:
         s = score_fn(x) if hi > lo else torch.empty(0, dtype=torch.float32, device=x.device)
-    return gather_samples(x, s)
+    return gather_samples(x, s, max_rows=-(-num_samples // world))       # ceil: every rank knows it, one collective
 
 
 # ---------------------------------------------------------------------------------------------------------
@@ -128,28 +165,29 @@ def item_seed(seed, index):
     return z ^ (z >> 31)
 
 
-def gather_tagged(tokens, scores, tags, group=None):
-    """One ragged all-gather of rows that carry an item tag: tokens (n, L), scores (n,) fp32 or None, tags (n,)
-    int64.  Returns the rows of all ranks sorted by (tag, original order): {tag: (tokens uint8, scores)}."""
-    t, s = gather_samples(tokens, scores, group=group)
-    # the tags ride along as a second byte matrix (8 bytes per row) in the same padded layout
-    tag_bytes = tags.to(torch.int64).contiguous().view(torch.uint8).reshape(-1, 8)
-    g, _ = gather_samples(tag_bytes, None, group=group)
-    all_tags = g.contiguous().view(torch.int64).reshape(-1)
+def gather_tagged(tokens, scores, tags, group=None, max_rows=None):
+    """One ragged all-gather of rows that carry an item tag: tokens (n, L) (None: this rank has no rows), scores (n,)
+    fp32 or None, tags (n,) int64.  Returns the rows of all ranks grouped by tag, original order inside a tag:
+    {tag: (tokens uint8, scores)}.  Tokens, scores and tags share the collective (`gather_rows`)."""
+    t, s, all_tags = gather_rows(tokens, scores, tags, max_rows=max_rows, group=group)
     out = {}
+    if all_tags is None:
+        return out
     for tag in sorted(set(all_tags.tolist())):
         rows = torch.nonzero(all_tags == tag).squeeze(-1)
         out[int(tag)] = (t[rows], None if s is None else s[rows])
     return out
 
 
-def run_cells(cells, run_cell, seed, rank=None, world=None, group=None):
+def run_cells(cells, run_cell, seed, rank=None, world=None, group=None, rows_per_cell=None):
     """Independent sampler calls dealt over the ranks (config 4: the (guidance strength, repeat) grid of pareto.py:131-164).
 
     cells: list of picklable descriptions, the same list on every rank.  run_cell(cell, key) -> (tokens (b, L) int,
     scores (b,) or None) runs ONE cell whole on the calling rank with `key = item_seed(seed, index)` as its Philox key
     (so a cell's samples do not depend on which rank, or how many ranks, ran the job).  Returns, on every rank, the
-    list of (tokens uint8, scores) in cell order after ONE all-gather of everything this rank produced."""
+    list of (tokens uint8, scores) in cell order after ONE all-gather of everything this rank produced.
+    rows_per_cell: the rows a cell yields when every cell yields the same (pareto.py: 200) -- makes the exchange a
+    single collective.  More ranks than cells is fine: a rank that was dealt nothing contributes no rows."""
     rank, world = _world(rank, world, group)
     mine = deal(len(cells), rank, world)
     toks, scs, tags = [], [], []
@@ -163,9 +201,9 @@ def run_cells(cells, run_cell, seed, rank=None, world=None, group=None):
             scs.append(sc.to(torch.float32))
     if world == 1:
         return [(toks[k].to(torch.uint8), scs[k] if have_scores else None) for k in range(len(cells))]
-    if not toks:        # more ranks than cells: an empty contribution (the collective still needs every rank)
-        raise ValueError('run_cells: every rank needs at least one cell (len(cells) >= world); run fewer ranks')
-    merged = gather_tagged(torch.cat(toks), torch.cat(scs) if have_scores else None, torch.cat(tags), group=group)
+    max_rows = None if rows_per_cell is None else rows_per_cell * (-(-len(cells) // world))
+    merged = gather_tagged(torch.cat(toks) if toks else None, torch.cat(scs) if (toks and have_scores) else None,
+                           torch.cat(tags) if toks else None, group=group, max_rows=max_rows if toks else None)
     return [merged[i] for i in range(len(cells))]
 
 
@@ -177,19 +215,31 @@ def share_members(local, n_members, rank=None, world=None, group=None):
     rank, world = _world(rank, world, group)
     if world == 1:
         return [local[m] for m in range(n_members)]
-    ref = next(iter(local.values()))
+    # a rank that owns no member (n_members < world) learns blob size and device from member 0's owner, rank 0
+    gloo = dist.get_backend(group) == 'gloo'
+    dev0 = next(iter(local.values())).device if local else torch.device('cpu' if (gloo or not torch.cuda.is_available()) else 'cuda')
+    numel = torch.tensor([local[0].numel() if 0 in local else 0], dtype=torch.int64, device='cpu' if gloo else dev0)
+    dist.broadcast(numel, src=0 if group is None else dist.get_global_rank(group, 0), group=group)
     out = []
     for m in range(n_members):
         owner = m % world
-        buf = local[m].contiguous() if owner == rank else torch.empty_like(ref)
+        buf = local[m].contiguous() if owner == rank else torch.empty(int(numel.item()), dtype=torch.float32, device=dev0)
         wire = buf.cpu() if (buf.is_cuda and dist.get_backend(group) == 'gloo') else buf
         dist.broadcast(wire, src=owner if group is None else dist.get_global_rank(group, owner), group=group)
         out.append(buf if wire is buf else wire.to(buf.device))
     return out
 
 
+def member_stream(seed, n_members):
+    """`pick_member` for `thompson_round`: Thompson picks from a numpy RandomState of their own (seeded like the round,
+    iterativeBO.py:202), independent of the global generator that project_sequences draws from."""
+    import numpy as np
+    rng = np.random.RandomState(int(seed) & 0xFFFFFFFF)
+    return lambda: int(rng.randint(0, n_members))
+
+
 def thompson_round(draw, consume, n_needed, max_draws, pick_member, seed, rank=None, world=None, group=None,
-                   per_rank=1, draw_many=None):
+                   per_rank=1, draw_many=None, rows_per_draw=None):
     """One acquisition round of Thompson sampling over an ensemble (iterativeBO.py:204-237) on `world` ranks.
 
     The reference loops: pick a member (numpy RNG), sample a small batch guided by it, hand the batch to update_data,
@@ -198,13 +248,19 @@ def thompson_round(draw, consume, n_needed, max_draws, pick_member, seed, rank=N
     wave[r * per_rank : (r + 1) * per_rank] -- and all-gathered once per wave; every rank then CONSUMES the wave in
     draw order and stops at the same draw the one-rank loop would have stopped at (draws of the wave beyond that point
     are dropped unseen).
-      pick_member() -> member index; called once per draw, in draw order, on EVERY rank (same numpy seed on all
-                       ranks, as util/seed.py sets it, keeps the streams in step);
+      pick_member() -> member index; called once per draw, in draw order, on EVERY rank, for a whole wave BEFORE any
+                       of its draws is computed or consumed.  For results that do not depend on `world` / `per_rank` it
+                       must therefore draw from a stream of its OWN (`member_stream(seed)` below): the reference
+                       interleaves `np.random.randint` with `inference(detokenize=True)` -> project_sequences, whose
+                       np.random.choice draws share numpy's GLOBAL generator (iterativeBO.py:213-234, sampling/base.py:
+                       44-63), so with the global generator the picks would shift with the wave size.  String repair
+                       keeps the global generator; the picks get their own;
       draw(member, key) -> (tokens (b, L), scores (b,) or None), this rank's sampler call;
       draw_many(members, keys) -> list of such pairs: per_rank draws stacked into ONE sampler call
                        (`Classifier_Guidance_Inpaint.inference_many`: one denoiser forward per step for all of them);
       consume(tokens uint8, scores) -> number of new sequences accepted (update_data on every rank, or on rank 0
                        with the count broadcast by the caller).
+      rows_per_draw: the sequences one draw yields (iterativeBO.py:130: 10) -- makes a wave's exchange one collective.
     Returns (n_new, n_draws_consumed)."""
     rank, world = _world(rank, world, group)
     n_new = k = 0
@@ -227,7 +283,7 @@ def thompson_round(draw, consume, n_needed, max_draws, pick_member, seed, rank=N
             have = outs[0][1] is not None
             scs = torch.cat([sc.to(torch.float32) for _, sc in outs]) if have else None
             tag = torch.cat([torch.full((x.shape[0],), wave[j], dtype=torch.int64, device=x.device) for j, (x, _) in zip(mine, outs)])
-            got = gather_tagged(toks, scs, tag, group=group)
+            got = gather_tagged(toks, scs, tag, group=group, max_rows=rows_per_draw * per_rank if rows_per_draw else None)
         for d in wave:
             if n_new >= n_needed or d >= max_draws:
                 break

@@ -85,6 +85,8 @@ def _load_dit_state(model_name, config):
 
 
 class MDLM(GenerativeModel):
+    NAN_WINDOW = 16
+
     def __init__(self, model_name, config, tokenizer, num_steps=128, seq_len=389, device='cuda', state_dict=None,
                  t_next_mode='reference', skip_unmasked=False):
         self.tokenizer = _instantiate_tokenizer(tokenizer)
@@ -112,7 +114,10 @@ class MDLM(GenerativeModel):
         self.global_batch = None        # set by a sharded caller: the unsharded batch size (NOS batchmean KL)
         self.noise_source = rt.NoiseSource(seed=torch.initial_seed())
         self.injected_noise = deque()   # parity runs: tensors consumed by successive sampling calls
-        self._nan_flag = torch.zeros(1, dtype=torch.int32, device=dev)
+        # one flag word per step of a check window: the sampling loop reads them every NAN_WINDOW steps and still names
+        # the first offending step, as the reference raises AT that step (models/mdlm.py:410-411)
+        self._nan_flags = torch.zeros(self.NAN_WINDOW, dtype=torch.int32, device=dev)
+        self._nan_flag = self._nan_flags[:1]
 
     # ------------------------------------------------------------------ noise bookkeeping
     def reseed(self, seed=None, row_offset=0):
@@ -282,13 +287,15 @@ class MDLM(GenerativeModel):
         return q_t
 
     @torch.no_grad()
-    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False, check=True):
+    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False, check=True, step=None):
         """One fused classifier-guidance step (sampling/cls_guidance.py:34-52): denoiser ->
         jump log-ratios -> reverse-step kernel.  Returns the next tokens (and p if asked).
 
         check: raise right here, as the reference does inside get_guided_rates / torch.multinomial, if the step met
         a NaN rate or a row it cannot sample from (one device-to-host read).  The sampling loop passes False and calls
-        `check_nan()` every few steps instead."""
+        `check_nan()` every few steps instead; `step` (its loop index) selects the flag word, so that the deferred
+        check still reports the step at which the rates went bad."""
+        self._select_nan_slot(step)
         mt, ms, sig_t = self._move_chances(t)
         logits = self._denoise_for_cg(x, sig_t)
         lr = slots = None
@@ -313,12 +320,13 @@ class MDLM(GenerativeModel):
         raise NotImplementedError(f'Diffusion type {self.diffusion} not implemented.')
 
     @torch.no_grad()
-    def guided_step_groups(self, x, t, groups, guide_temp):
+    def guided_step_groups(self, x, t, groups, guide_temp, step=None):
         """One guided step for SEVERAL independent sampler calls stacked in one batch (Thompson draws of an ensemble,
         iterativeBO.py:204-237): ONE denoiser forward over all rows, then per group its own value function's jump ratios
         and its own reverse step with its own Philox stream.  groups: [(predictor_model, NoiseSource, lo, hi)], rows
         [lo, hi) of x.  A row's logits do not depend on the batch it is in (tests: batch-size invariance), so every group
         gets exactly the tokens its own `guided_step` call would have produced."""
+        self._select_nan_slot(step)
         mt, ms, sig_t = self._move_chances(t)
         logits = self._denoise_for_cg(x, sig_t)
         x_out = torch.empty_like(x)
@@ -361,15 +369,31 @@ class MDLM(GenerativeModel):
         cache[key] = (groups, out)
         return out
 
+    def _select_nan_slot(self, step):
+        slot = 0 if step is None else int(step) % self.NAN_WINDOW
+        self._nan_flag = self._nan_flags[slot:slot + 1]
+        if step is not None:
+            self._nan_steps = getattr(self, '_nan_steps', {})
+            self._nan_steps[slot] = int(step)
+
     def check_nan(self):
-        """The reference's two failure modes of a guided step, read back from the kernel's flag: NaN rates
-        (`raise ValueError`, models/mdlm.py:410-411) and a row torch.multinomial would refuse (cls_guidance.py:52)."""
-        flag = int(self._nan_flag.item())
-        if flag:
-            self._nan_flag.zero_()
-            if flag & 1:
-                raise ValueError("The rate matrix 'q_t' contains NaNs.")
-            raise RuntimeError('invalid multinomial distribution (sum of guided rates is 0, inf or nan)')
+        """The reference's two failure modes of a guided step, read back from the kernels' flag words: NaN rates
+        (`raise ValueError`, models/mdlm.py:410-411) and a row torch.multinomial would refuse (cls_guidance.py:52).
+        Names the first offending step of the window (one flag word per step) and both conditions if both occurred."""
+        flags = self._nan_flags.cpu().tolist()
+        if not any(flags):
+            return
+        steps = getattr(self, '_nan_steps', {})
+        bad = sorted((steps.get(slot, -1), slot) for slot, f in enumerate(flags) if f)
+        step, slot = bad[0]
+        flag = flags[slot]
+        self._nan_flags.zero_()
+        self._nan_steps = {}
+        where = f' (first at reverse step index {step})' if step >= 0 else ''
+        also = ' -- and the guided rates of a row sum to 0, inf or nan (torch.multinomial would refuse it)' if flag == 3 else ''
+        if flag & 1:
+            raise ValueError(f"The rate matrix 'q_t' contains NaNs.{where}{also}")
+        raise RuntimeError(f'invalid multinomial distribution (sum of guided rates is 0, inf or nan){where}')
 
     def _nos_denoise(self, classifier_model, num_nos_steps, nos_step_size, nos_stability_coef, xt, t):
         from .nos_step import nos_denoise

@@ -36,9 +36,10 @@ class Classifier_Guidance_Inpaint(Algo):
         check = getattr(self.net, 'check_nan', None) if fused else None
         for i, t in enumerate(timesteps):
             if fused:
-                x = self.net.guided_step(x, t, self.forward_op, self.temperature, check=False)
-                # the reference raises at the offending step (models/mdlm.py:410-411); reading the kernel's flag costs a
-                # device sync, so it is read every NAN_CHECK_EVERY steps and after the last one
+                x = self.net.guided_step(x, t, self.forward_op, self.temperature, check=False, step=i)
+                # the reference raises at the offending step (models/mdlm.py:410-411); reading the kernels' flags costs a
+                # device sync, so they are read every NAN_CHECK_EVERY steps and after the last one -- one flag word per
+                # step of the window, so the error still names the step
                 if check is not None and (i + 1) % self.NAN_CHECK_EVERY == 0:
                     check()
             else:
@@ -68,7 +69,7 @@ class Classifier_Guidance_Inpaint(Algo):
                   for i, (op, sd) in enumerate(zip(forward_ops, seeds))]
         x = self.net.get_start(n * num_samples)
         for i, t in enumerate(timesteps):
-            x = self.net.guided_step_groups(x, t, groups, self.temperature)
+            x = self.net.guided_step_groups(x, t, groups, self.temperature, step=i)
             if (i + 1) % self.NAN_CHECK_EVERY == 0:
                 self.net.check_nan()
             if inpaint:

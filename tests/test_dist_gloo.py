@@ -151,6 +151,48 @@ def _worker_cells(rank, world, port, q):
             ok = ok and _thompson(world, rank, n_needed, max_draws) == _thompson(1, 0, n_needed, max_draws)
             # several draws stacked per rank and wave (draw_many): still the one-rank, one-draw-at-a-time result
             ok = ok and _thompson(world, rank, n_needed, max_draws, per_rank=3) == _thompson(1, 0, n_needed, max_draws)
+        # -- round 3 --------------------------------------------------------------------------------------------
+        # fewer cells / members than ranks: the rank that was dealt nothing contributes nothing, nobody hangs or raises
+        one = run_cells(cells[:1], _stub_cell, seed=42)
+        ok = ok and len(one) == 1 and torch.equal(one[0][0], want[0][0]) and torch.equal(one[0][1], want[0][1])
+        blobs = share_members({0: torch.arange(7.)} if rank == 0 else {}, 1)
+        ok = ok and len(blobs) == 1 and torch.equal(blobs[0], torch.arange(7.))
+        # a batch costs ONE collective when the row bound is known beforehand; two without it
+        calls = []
+        real = dist.all_gather_into_tensor
+        dist.all_gather_into_tensor = lambda *a, **k: (calls.append(a[0].numel()), real(*a, **k))[1]
+        try:
+            uniform = [(c, r, 4) for r in range(3) for c in (0.1, 1.0, 10.0)]
+            got2 = run_cells(uniform, _stub_cell, seed=42, rows_per_cell=4)
+            n_fast = len(calls)
+            run_cells(uniform, _stub_cell, seed=42)
+            n_ragged = len(calls) - n_fast
+            full = torch.randint(0, 31, (10, 13), generator=torch.Generator().manual_seed(0))
+            lo, hi = shard_bounds(10, rank, world)
+            before = len(calls)
+            t, s_ = gather_samples(full[lo:hi], full[lo:hi].float().sum(1), max_rows=5)
+            n_rows_call = len(calls) - before
+        finally:
+            dist.all_gather_into_tensor = real
+        want2 = run_cells(uniform, _stub_cell, seed=42, rank=0, world=1)
+        ok = ok and all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(got2, want2))
+        ok = ok and (n_fast, n_ragged, n_rows_call) == (1, 2, 1) and torch.equal(t.long(), full)
+        # Thompson picks from their own stream (member_stream): draws that use numpy's GLOBAL generator in between (the
+        # reference's project_sequences does) leave the picks, and with them the round, independent of the wave size
+        from sgpo_amd.dist import member_stream, thompson_round
+        import numpy as np
+
+        def noisy_draw(member, key):
+            np.random.rand(3)                           # what string repair does to the global generator
+            return _stub_draw(member, key)
+        res = []
+        for w, r, pr in ((world, rank, 1), (world, rank, 3), (1, 0, 1)):
+            np.random.seed(5)
+            st = _Store(20)
+            many = (lambda ms, ks: [noisy_draw(m, k) for m, k in zip(ms, ks)]) if pr > 1 else None
+            res.append((thompson_round(noisy_draw, st.consume, 20, 50, member_stream(11, 10), seed=3, rank=r, world=w,
+                                       per_rank=pr, draw_many=many, rows_per_draw=6), st.rows))
+        ok = ok and res[0] == res[2] and res[1] == res[2]
         q.put((rank, ok))
     finally:
         dist.destroy_process_group()

@@ -451,6 +451,39 @@ def test_skip_unmasked_is_bit_identical_over_a_whole_run(env):
     assert 0.25 < frac < 0.5, frac
 
 
+def test_deferred_nan_check_names_the_offending_step(env):
+    """the sampling loop reads the kernels' NaN flags every NAN_CHECK_EVERY steps; the error must still
+    name the step at which the rates went bad (the reference raises at that step, models/mdlm.py:410-411).  A value
+    function whose head turns NaN from step 5 on: ValueError naming step index 5, raised at the window's check."""
+    from problem.protein import ProteinPredictor
+    from sgpo_amd import weights as W
+    g = load_golden('cg_small_guided')
+    T, temp = 40, float(g['temp'])
+    Lq = g['x'].shape[1]
+    full_seq = bytes(g['full_seq'].numpy().tolist()).decode()
+    net, pred, algo, sd, msd = _build(g, T, Lq, full_seq, temp, int(g['mlp_seed']))
+    bad_sd = {k: v.clone() for k, v in msd.items()}
+    bad_sd['cls_head.2.weight'] = torch.full_like(bad_sd['cls_head.2.weight'], float('nan'))   # (the bias cancels in f(jump) - f(x))
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq=full_seq, residues=None)
+    bad = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+    bad.model.load_state_dict(bad_sd)
+    bad.eval()
+    real_step, seen = net.guided_step, []
+
+    def step(x, t, predictor, temperature, **kw):
+        seen.append(kw.get('step'))
+        return real_step(x, t, bad if kw.get('step', 0) >= 5 else predictor, temperature, **kw)
+    net.guided_step = step
+    net.reseed(3)
+    with pytest.raises(ValueError, match='NaN') as err:
+        algo.inference(num_samples=4)
+    assert 'step index 5' in str(err.value), str(err.value)
+    assert seen[-1] == algo.NAN_CHECK_EVERY - 1          # raised at the first window check, not at the end of the run
+    net.guided_step = real_step
+    net.reseed(3)
+    algo.inference(num_samples=4)                          # the flags were cleared: a clean run passes
+
+
 UDLM_CFG = dict(diffusion='uniform', parameterization='d3pm', time_conditioning=True)    # configs/model/udlm.yaml:6-9
 
 

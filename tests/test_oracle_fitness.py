@@ -28,3 +28,28 @@ def test_restatement_matches_reference_goldens():
     assert float((g['CreiLOV_y'] - g['CreiLOV_y_nopenalty']).abs().max()) > 0
     # residue combos are compared with the first len(combo) letters of the parent (zip truncation)
     assert oe.penalty(71, 70, 0.99) == 0.99 and oe.penalty(70, 70, 0.99) == 1
+
+
+def test_restatement_on_the_shipped_ensemble_scores_the_reference_free_run():
+    """The reference's 64-sequence guided free run (free_run_real.npz) was scored by the reference's inference_oracle
+    on its shipped CreiLOV ensemble; the restatement on the exported copy of those weights (oracle/_ref/CreiLOV_ens,
+    written by __graft_entry__.build() where the reference checkout exists) reproduces those numbers."""
+    import os
+
+    import pytest
+
+    from conftest import ROOT
+    from oracle import oracle_ensemble as oe
+    ens = os.path.join(ROOT, 'oracle', '_ref', 'CreiLOV_ens')
+    if not os.path.isdir(ens):
+        pytest.skip('oracle/_ref/CreiLOV_ens missing (no reference checkout at build time)')
+    g = load_golden('free_run_real')
+    alphabet = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+    seqs = [''.join(alphabet[int(t)] for t in row) for row in g['repaired']]
+    parent = bytes(g['full_seq'].numpy().tolist()).decode()
+    states = [torch.load(os.path.join(ens, str(f)), map_location='cpu', weights_only=True) for f in g['member_files']]
+    y = oe.ensemble_fitness(states, seqs, parent, 'CreiLOV')
+    torch.testing.assert_close(y.double(), torch.as_tensor(g['fitness']).double(), rtol=1e-6, atol=1e-8)
+    y0 = oe.ensemble_fitness(states, seqs, parent, 'CreiLOV', impose_penalty=False)
+    torch.testing.assert_close(y0.double(), torch.as_tensor(g['fitness_nopenalty']).double(), rtol=1e-6, atol=1e-8)
+    assert float(y.mean()) > 0 and float((y0 - y).abs().max()) > 0      # the Hamming penalty is active on these samples

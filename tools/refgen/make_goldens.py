@@ -729,6 +729,77 @@ def gen_oracle_ens():
         sys.modules.update(saved)
 
 
+def gen_free_run():
+    """north_star's third check at real dims, joined to row f-1: a guided FREE run of the reference (MDLM +
+    Classifier_Guidance_Inpaint, real DiT dims, CreiLOV, all 127 steps, temperature 0.064, detokenize=True ->
+    project_sequences) of 64 sequences, scored by the reference's own inference_oracle on the SHIPPED CreiLOV ensemble
+    (oracle/checkpoints/CreiLOV, weights-only load).  Stores the tokens, the repaired strings and their fitness; the GPU
+    test compares per-position marginals, Shannon entropy and fitness mean of >= 1024 device samples against these."""
+    import time
+    import types
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, T, temp, seed = 64, 119, 128, 0.064, 91
+    net, core, sd = build_ref_mdlm(REAL, seed=16, L=L, T=T)
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=CREILOV, residues=None))
+    pred, msd = build_ref_mlp(L, None, seed=34, full_len=L)
+    algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred, temperature=temp, device='cpu')
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    t0 = time.time()
+    with torch.no_grad():
+        x, seqs = algo.inference(num_samples=B, detokenize=True)
+    print(f'reference free run, B = {B}: {time.time() - t0:.1f} s')
+    with torch.no_grad():
+        vf = pred.log_likelihood(x)
+    # the reference's fitness oracle on its shipped ensemble (same module juggling as gen_oracle_ens)
+    bio = standins._mod('Bio')
+    seqio = standins._mod('Bio.SeqIO')
+
+    def _parse(path, fmt):
+        recs, cur = [], None
+        for line in open(path):
+            line = line.strip()
+            if line.startswith('>'):
+                cur = types.SimpleNamespace(id=line[1:], seq='')
+                recs.append(cur)
+            elif cur is not None:
+                cur.seq += line
+        return recs
+    seqio.parse = _parse
+    seqio.read = lambda path, fmt: _parse(path, fmt)[0]
+    bio.SeqIO = seqio
+    standins._mod('wandb')
+    cwd = os.getcwd()
+    os.chdir(REF)
+    saved = {k: v for k, v in sys.modules.items() if k == 'oracle' or k.startswith('oracle.')}
+    _orig_load = torch.load
+    try:
+        for k in saved:
+            del sys.modules[k]
+        pkg = types.ModuleType('oracle')
+        pkg.__path__ = [os.path.join(REF, 'oracle')]
+        sys.modules['oracle'] = pkg
+        from oracle.inference_oracle import inference_oracle
+        parent = str(_parse('data/CreiLOV/parent.fasta', 'fasta')[0].seq)
+        assert parent == CREILOV
+        torch.load = lambda f, **kw: _orig_load(f, **{'map_location': 'cpu', 'weights_only': True, **kw})
+        _, y = inference_oracle(seqs, protein='CreiLOV', model_path='oracle/checkpoints/CreiLOV')
+        _, y_np = inference_oracle(seqs, protein='CreiLOV', model_path='oracle/checkpoints/CreiLOV', impose_penalty=False)
+        files = os.listdir('oracle/checkpoints/CreiLOV')
+    finally:
+        torch.load = _orig_load
+        os.chdir(cwd)
+        for k in [k for k in sys.modules if k == 'oracle' or k.startswith('oracle.')]:
+            del sys.modules[k]
+        sys.modules.update(saved)
+    aa = standins.ALPHABET
+    toks = torch.tensor([[aa.index(c) for c in s_] for s_ in seqs])
+    save('free_run_real', seed=16, mlp_seed=34, dims=np.array(list(REAL.values())), T=T, temp=temp, run_seed=seed, x=x.to(torch.int8),
+         repaired=toks.to(torch.int8), fitness=y.numpy(), fitness_nopenalty=y_np.numpy(), value_function=vf,
+         member_files=np.array(files), full_seq=np.frombuffer(CREILOV.encode(), dtype=np.uint8))
+    print('fitness mean', float(y.mean()), 'no penalty', float(y_np.mean()), 'value function mean', float(vf.mean()))
+
+
 def gen_acquire():
     """f-2: the reference's own Algo.project_sequences (sampling/base.py:40-63) and
     ProteinPredictorDataset.update_data (dataset/protein.py:153-213) on scripted inputs.  numpy's
@@ -984,7 +1055,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(free_run=gen_free_run, cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
