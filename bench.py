@@ -442,6 +442,8 @@ def run_other(a, dist, device, backend, rank, world):
         dt = _max_over_ranks(dist, backend, dt, device)
     dt_prof = dt
     if not a.no_prof and not prof_in_timed_region:
+        graphs = getattr(wl.net, 'use_graphs', False)
+        wl.net.use_graphs = False        # the per-kernel events are recorded by eager launches, not by graph replays
         L.check(lib.sgpo_prof_enable(1, wl.n_launches(a.steps)), 'prof_enable')
         t1 = time.perf_counter()
         for i in range(a.steps):
@@ -479,9 +481,14 @@ def run_other(a, dist, device, backend, rank, world):
             roof['denoiser_tflops'] = round(gf / (gt * 1e-3) / 1e12, 2)
         roof['gpu_busy_frac'] = round(tot * 1e-3 / dt_prof, 4)
         if not prof_in_timed_region:
+            wl.net.use_graphs = graphs
             roof['note'] = ('kernel durations from a second pass over the same %d steps with per-kernel events on (%.1f ms per step '
                             'there): at this batch size the event records themselves are 40-60 %% of the wall clock, so the timed '
-                            'region runs without them' % (a.steps, 1e3 * dt_prof / a.steps))
+                            'region runs without them; gpu_busy_frac = kernel time of that pass / wall clock of the TIMED region '
+                            '(about 1: the small batches are bound by the per-kernel fixed cost on the GPU, not by launch gaps -- '
+                            'replaying the loop from a recorded HIP graph, MDLM.use_graphs, changes the wall clock by 1-2 %%)'
+                            % (a.steps, 1e3 * dt_prof / a.steps))
+            roof['gpu_busy_frac'] = round(tot * 1e-3 / dt, 4)
     if rank != 0:
         return None
     cpu = wl.cpu_baseline() if (not a.no_cpu_baseline and world == 1) else None

@@ -104,6 +104,16 @@ int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* l
                            uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
                            void* stream);
 
+/* The same step with the Philox key in DEVICE memory, for callers that record the sampling loop into a HIP graph and
+ * replay it with a new seed (no counterpart in the reference, whose noise comes from torch's global generator):
+ * key_dev[0] = seed, key_dev[1] = first global row of this shard (rows, i.e. sequences x L), key_dev[2] = base added to
+ * `offset` (the call index inside the loop), key_dev[3] unused.  In-kernel Philox only; other arguments as above. */
+int sgpo_reverse_step_mdlm_devkey(const float* logits, const int64_t* x, const float* log_ratio,
+                                  const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
+                                  float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
+                                  uint64_t offset, const uint64_t* key_dev, int64_t* x_out, float* probs_out,
+                                  int* nan_flag, void* stream);
+
 /* UDLM variant: _d3pm_parameterization + _compute_posterior (mdlm_diffusion.py:343-348, 392-419)
  * + models/mdlm.py:87-95.  step_mode SOFT or HARD. */
 int sgpo_reverse_step_udlm(const float* logits, const int64_t* x, int B, int L, int K,
@@ -147,6 +157,10 @@ int sgpo_categorical_sample(const float* probs, int64_t rows, int K, int noise_m
 int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, const int* read_pos, int alphabet,
                     int hidden, int time_conditioned, sgpo_mlp** out);
 void sgpo_mlp_destroy(sgpo_mlp* m);
+/* dst <- the weights of src (same architecture, same read positions), in place and asynchronous on `stream`: launches
+ * recorded with dst (a HIP graph of stacked Thompson draws, iterativeBO.py:204-237) see the new ensemble member on their
+ * next replay.  No counterpart in the reference (`update_model(member)` there swaps Python objects). */
+int sgpo_mlp_copy(sgpo_mlp* dst, const sgpo_mlp* src, void* stream);
 /* forward(seq, t): x [B][L], t [B] (NULL = zeros, log_likelihood of problem/protein.py:37-38) -> out [B] */
 int sgpo_mlp_forward(sgpo_mlp* m, const int64_t* x, const float* t, int B, int L, float* out, void* stream);
 /* Exact guidance log-ratios of get_guided_rates (models/mdlm.py:360-375, models/d3pm.py:146-161)
@@ -178,6 +192,15 @@ int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* members, const i
                                  const uint64_t* row_offsets, const int* slot_of_pos, float* log_ratio,
                                  size_t log_ratio_bytes, void* workspace, size_t workspace_bytes, int64_t* x_out,
                                  int* nan_flag, void* stream);
+/* The same with the draws' Philox keys in DEVICE memory (HIP-graph replay with new seeds; see
+ * sgpo_reverse_step_mdlm_devkey): keys_dev [n_groups][4] = seed, first global row, offset base, unused; `offset` is
+ * the call index inside the loop, the same for every draw.  At most 1024 draws. */
+int sgpo_guided_step_groups_mdlm_devkey(int n_groups, sgpo_mlp* const* members, const int* row_lo, const float* logits,
+                                        const int64_t* x, int L, int K, int S, float t, int mask_index,
+                                        float move_chance_t, float move_chance_s, float guide_temp, uint64_t offset,
+                                        const uint64_t* keys_dev, const int* slot_of_pos, float* log_ratio,
+                                        size_t log_ratio_bytes, void* workspace, size_t workspace_bytes, int64_t* x_out,
+                                        int* nan_flag, void* stream);
 /* sgpo_guidance_ratio_mlp_absorbing for callers that cannot allocate.  No counterpart in the reference: it is for
  * code under HIP graph capture, tight serving loops and harnesses that forbid hipMalloc, which have no way to
  * provide the workspace.  Same arguments minus the workspace, same kernels, same bits in log_ratio.  The

@@ -37,6 +37,7 @@ SIGNATURES = {
     'sgpo_dit_forward': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp, _vp, _vp, _vp, _sz, _vp]),
     'sgpo_reverse_step_mdlm': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _i, _vp, _u64, _u64,
                                     _u64, _vp, _vp, _vp, _vp]),
+    'sgpo_reverse_step_mdlm_devkey': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _i, _f, _f, _f, _i, _u64, _vp, _vp, _vp, _vp, _vp]),
     'sgpo_reverse_step_udlm': (_i, [_vp, _vp, _i, _i, _i, _f, _f, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp, _vp]),
     'sgpo_guided_step_udlm': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _f, _f, _i, _vp, _u64, _u64, _u64, _vp, _vp, _vp, _vp]),
     'sgpo_q_sample_udlm': (_i, [_vp, _vp, _i, _i, _i, _i, _vp, _vp, _u64, _u64, _u64, _vp, _vp]),
@@ -44,12 +45,15 @@ SIGNATURES = {
     'sgpo_categorical_sample': (_i, [_vp, _i64, _i, _i, _vp, _u64, _u64, _u64, _vp, _vp]),
     'sgpo_mlp_create': (_i, [_vp, _sz, _i, C.POINTER(_i), _i, _i, _i, C.POINTER(_vp)]),
     'sgpo_mlp_destroy': (None, [_vp]),
+    'sgpo_mlp_copy': (_i, [_vp, _vp, _vp]),
     'sgpo_mlp_forward': (_i, [_vp, _vp, _vp, _i, _i, _vp, _vp]),
     'sgpo_mlp_workspace_bytes': (_sz, [_vp, _i]),
     'sgpo_guidance_ratio_mlp': (_i, [_vp, _vp, _f, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sgpo_guidance_ratio_mlp_absorbing': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp, _sz, _vp]),
     'sgpo_guided_step_groups_mdlm': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _f, _vp, _vp, _vp, _vp, _vp, _sz,
                                           _vp, _sz, _vp, _vp, _vp]),
+    'sgpo_guided_step_groups_mdlm_devkey': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _f, _u64, _vp, _vp, _vp, _sz,
+                                                 _vp, _sz, _vp, _vp, _vp]),
     'sgpo_guidance_noalloc_max_bytes': (_sz, []),
     'sgpo_guidance_ratio_mlp_absorbing_noalloc': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     'sgpo_fitness_create': (_i, [_vp, _sz, _i, _i, _i, C.POINTER(_vp)]),

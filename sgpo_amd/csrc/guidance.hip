@@ -73,6 +73,33 @@ extern "C" void sgpo_mlp_destroy(sgpo_mlp* m) {
   delete m;
 }
 
+// dst <- the weights of src (same architecture and read positions), asynchronously on `stream`: every device table is
+// overwritten in place, so launches recorded with dst's pointers (a HIP graph of stacked Thompson draws) see the new
+// member on their next replay.
+extern "C" int sgpo_mlp_copy(sgpo_mlp* dst, const sgpo_mlp* src, void* stream) {
+  SGPO_REQUIRE(dst && src, "mlp_copy: null argument");
+  SGPO_REQUIRE(dst->n_read == src->n_read && dst->alphabet == src->alphabet && dst->hidden == src->hidden &&
+               dst->time_cond == src->time_cond && dst->n_params == src->n_params,
+               "mlp_copy: the value functions differ in shape (%d/%d read positions, %d/%d letters)", dst->n_read, src->n_read,
+               dst->alphabet, src->alphabet);
+  for (int i = 0; i < src->n_read; ++i)
+    SGPO_REQUIRE(dst->read_pos_host[i] == src->read_pos_host[i], "mlp_copy: read position %d differs", i);
+  if (dst == src) return SGPO_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const size_t h = MH, A = src->alphabet;
+#define CP(field, n) SGPO_CHECK_HIP(hipMemcpyAsync(dst->field, src->field, (n) * sizeof(float), hipMemcpyDeviceToDevice, st))
+  CP(params, src->n_params);
+  CP(T1, (size_t)src->n_read * A * h);
+  CP(be1, h);
+  CP(w1t_time, h * h);
+  CP(wt_lin_t, h * h);
+  for (int i = 0; i < 3; ++i) CP(w_t[i], h * h);
+  CP(w_perm, 3 * h * h);
+  CP(bias_perm, 4 * h);
+#undef CP
+  return SGPO_OK;
+}
+
 extern "C" int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, const int* read_pos, int alphabet,
                                int hidden, int time_conditioned, sgpo_mlp** out) {
   SGPO_REQUIRE(blob && read_pos && out, "mlp_create: null argument");
@@ -85,6 +112,7 @@ extern "C" int sgpo_mlp_create(const float* blob, size_t n_floats, int n_read, c
   sgpo_mlp* m = new sgpo_mlp();
   m->n_read = n_read; m->alphabet = alphabet; m->hidden = hidden; m->time_cond = time_conditioned;
 #define HIPF(e) do { hipError_t _e = (e); if (_e != hipSuccess) { sgpo_set_error("%s: %s", #e, hipGetErrorString(_e)); sgpo_mlp_destroy(m); return SGPO_ERR_HIP; } } while (0)
+  m->n_params = n_floats;
   HIPF(hipMalloc((void**)&m->params, n_floats * 4));
   HIPF(hipMemcpy(m->params, blob, n_floats * 4, hipMemcpyDeviceToDevice));
   HIPF(hipMalloc((void**)&m->read_pos, n_read * sizeof(int)));
@@ -431,6 +459,24 @@ extern "C" size_t sgpo_mlp_workspace_bytes(const sgpo_mlp* m, int B) {
          al256((size_t)B * 2 * m->n_read * sizeof(unsigned short));
 }
 
+// log_ratio <- 0 by a kernel of the library's own: a hipMemsetAsync recorded into a HIP graph as a memset node did not
+// reliably clear the buffer on replay (round 3: NaN rates at a later step of a recorded sampling loop)
+__global__ __launch_bounds__(256) void zero_f32_kernel(float* __restrict__ p, size_t n) {
+  size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  const size_t stride = (size_t)gridDim.x * 256 * 4;
+  for (; i + 3 < n; i += stride) *reinterpret_cast<float4*>(p + i) = float4{0.f, 0.f, 0.f, 0.f};
+  if (i < n) for (size_t j = i; j < n && j < i + 4; ++j) p[j] = 0.f;
+}
+static int launch_zero_f32(float* p, size_t n, hipStream_t st) {
+  if (n == 0) return SGPO_OK;
+  SGPO_REQUIRE(((uintptr_t)p & 15) == 0, "zero_f32: buffer must be 16-byte aligned");
+  size_t blocks = (n / 4 + 255) / 256 + 1;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, st, p, n);
+  SGPO_CHECK_HIP(hipGetLastError());
+  return SGPO_OK;
+}
+
 static int guidance_ratio(sgpo_mlp* m, const int64_t* x, float t, int B, int L, int S, int mask_index, float* log_ratio,
                           void* workspace, size_t workspace_bytes, void* stream) {
   SGPO_REQUIRE(m && x && log_ratio && workspace, "guidance_ratio_mlp: null argument");
@@ -448,7 +494,8 @@ static int guidance_ratio(sgpo_mlp* m, const int64_t* x, float t, int B, int L, 
   int* cnt = (int*)(w + al256((size_t)B * MH * sizeof(float)));
   unsigned short* lists = (unsigned short*)((char*)cnt + al256((size_t)B * 2 * sizeof(int)));
   const bool compact = mask_index >= 0;
-  if (compact) SGPO_CHECK_HIP(hipMemsetAsync(log_ratio, 0, (size_t)B * m->n_read * S * sizeof(float), st));
+  if (compact)
+    if (int rc = launch_zero_f32(log_ratio, (size_t)B * m->n_read * S, st)) return rc;
   {
     ProfScope prof_scope(PK_MLP_BASE, st, (double)B * m->n_read * MH * 4.0);
     hipLaunchKernelGGL(mlp_base_kernel, dim3(B), dim3(64), 0, st, mlp_dev(m), x, (const float*)nullptr, t, L, hpre,
@@ -488,13 +535,19 @@ extern "C" int sgpo_guidance_ratio_mlp_absorbing(sgpo_mlp* m, const int64_t* x, 
 // draws (blockIdx.y picks the draw; inside a draw every index is that of its own launch, so the tokens are the same bit
 // for bit) instead of four small launches per draw: ten draws of ten sequences were forty launches a step, a quarter of
 // the step's GPU time and most of its launch gaps.
-extern "C" int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* members, const int* row_lo, const float* logits,
-                                            const int64_t* x, int L, int K, int S, float t, int mask_index,
-                                            float move_chance_t, float move_chance_s, float guide_temp,
-                                            const uint64_t* seeds, const uint64_t* offsets, const uint64_t* row_offsets,
-                                            const int* slot_of_pos, float* log_ratio, size_t log_ratio_bytes,
-                                            void* workspace, size_t workspace_bytes, int64_t* x_out, int* nan_flag,
-                                            void* stream) {
+static int guided_step_groups_impl(int n_groups, sgpo_mlp* const* members, const int* row_lo, const float* logits,
+                                   const int64_t* x, int L, int K, int S, float t, int mask_index,
+                                   float move_chance_t, float move_chance_s, float guide_temp,
+                                   const uint64_t* seeds, const uint64_t* offsets, const uint64_t* row_offsets,
+                                   const int* slot_of_pos, float* log_ratio, size_t log_ratio_bytes,
+                                   void* workspace, size_t workspace_bytes, int64_t* x_out, int* nan_flag,
+                                   const uint64_t* keys_dev, void* stream) {
+  static const uint64_t zeros[1024] = {0};
+  if (keys_dev) {   // the keys come from device memory: the host arrays are not read (seed, first row), offsets[] may be null
+    SGPO_REQUIRE(n_groups <= 1024, "guided_step_groups_devkey: %d draws (at most 1024)", n_groups);
+    seeds = zeros; row_offsets = zeros;
+    if (!offsets) offsets = zeros;
+  }
   SGPO_REQUIRE(n_groups > 0 && members && row_lo && logits && x && seeds && offsets && row_offsets && x_out,
                "guided_step_groups: null argument");
   SGPO_REQUIRE(L > 0 && K > 0 && row_lo[0] >= 0, "guided_step_groups: L=%d K=%d first row %d", L, K, row_lo[0]);
@@ -528,7 +581,7 @@ extern "C" int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* membe
     hpre = (float*)w;
     cnt = (int*)(w + al256((size_t)B * MH * sizeof(float)));
     lists = (unsigned short*)((char*)cnt + al256((size_t)B * 2 * sizeof(int)));
-    SGPO_CHECK_HIP(hipMemsetAsync(log_ratio, 0, need_lr, st));
+    if (int rc = launch_zero_f32(log_ratio, need_lr / sizeof(float), st)) return rc;
   }
   for (int g0 = 0; g0 < n_groups; g0 += SGPO_MAX_GROUPS) {
     const int ng = n_groups - g0 < SGPO_MAX_GROUPS ? n_groups - g0 : SGPO_MAX_GROUPS;
@@ -570,10 +623,36 @@ extern "C" int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* membe
     SGPO_CHECK_HIP(hipGetLastError());
     if (int rc = launch_reverse_step_mdlm_groups(rs, max_seq, logits, x, first ? log_ratio : nullptr, first ? slot_of_pos : nullptr,
                                                  first ? first->n_read : L, L, K, mask_index, move_chance_t, move_chance_s,
-                                                 guide_temp, x_out, nan_flag, st))
+                                                 guide_temp, x_out, nan_flag, st, keys_dev, g0))
       return rc;
   }
   return SGPO_OK;
+}
+
+extern "C" int sgpo_guided_step_groups_mdlm(int n_groups, sgpo_mlp* const* members, const int* row_lo, const float* logits,
+                                            const int64_t* x, int L, int K, int S, float t, int mask_index,
+                                            float move_chance_t, float move_chance_s, float guide_temp,
+                                            const uint64_t* seeds, const uint64_t* offsets, const uint64_t* row_offsets,
+                                            const int* slot_of_pos, float* log_ratio, size_t log_ratio_bytes,
+                                            void* workspace, size_t workspace_bytes, int64_t* x_out, int* nan_flag,
+                                            void* stream) {
+  return guided_step_groups_impl(n_groups, members, row_lo, logits, x, L, K, S, t, mask_index, move_chance_t, move_chance_s,
+                                 guide_temp, seeds, offsets, row_offsets, slot_of_pos, log_ratio, log_ratio_bytes, workspace,
+                                 workspace_bytes, x_out, nan_flag, nullptr, stream);
+}
+
+extern "C" int sgpo_guided_step_groups_mdlm_devkey(int n_groups, sgpo_mlp* const* members, const int* row_lo,
+                                                   const float* logits, const int64_t* x, int L, int K, int S, float t,
+                                                   int mask_index, float move_chance_t, float move_chance_s, float guide_temp,
+                                                   uint64_t offset, const uint64_t* keys_dev, const int* slot_of_pos,
+                                                   float* log_ratio, size_t log_ratio_bytes, void* workspace,
+                                                   size_t workspace_bytes, int64_t* x_out, int* nan_flag, void* stream) {
+  SGPO_REQUIRE(keys_dev != nullptr && n_groups > 0 && n_groups <= 1024, "guided_step_groups_devkey: null keys or %d draws", n_groups);
+  uint64_t offs[1024];
+  for (int g = 0; g < n_groups; ++g) offs[g] = offset;
+  return guided_step_groups_impl(n_groups, members, row_lo, logits, x, L, K, S, t, mask_index, move_chance_t, move_chance_s,
+                                 guide_temp, nullptr, offs, nullptr, slot_of_pos, log_ratio, log_ratio_bytes, workspace,
+                                 workspace_bytes, x_out, nan_flag, keys_dev, stream);
 }
 
 // ---- the same call for callers that cannot allocate -----------------------------------------

@@ -6,6 +6,7 @@
 
 struct sgpo_mlp {
   int n_read = 0, alphabet = 0, hidden = 0, time_cond = 0;
+  size_t n_params = 0;         // floats in `params`
   int* read_pos = nullptr;     // [n_read] device
   int* read_pos_host = nullptr;
   float* params = nullptr;     // raw blob copy
@@ -36,4 +37,5 @@ struct RsGroups {
 int launch_reverse_step_mdlm_groups(const RsGroups& gs, int max_seq, const float* logits, const int64_t* x,
                                     const float* log_ratio, const int* slot_of_pos, int n_slots, int L, int K,
                                     int mask_index, float move_chance_t, float move_chance_s, float guide_temp,
-                                    int64_t* x_out, int* nan_flag, hipStream_t stream);
+                                    int64_t* x_out, int* nan_flag, hipStream_t stream, const uint64_t* key_dev = nullptr,
+                                    int key_g0 = 0);

@@ -149,13 +149,19 @@ __global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
     const int* __restrict__ slot_of_pos, int n_slots, int rows, int L, int K, int mask_index, float mt, float ms,
     float guide_temp, int step_mode, int noise_mode, const float* __restrict__ noise, uint64_t seed,
     uint64_t offset, uint64_t row_offset, int64_t* __restrict__ x_out, float* __restrict__ probs_out,
-    int* __restrict__ nan_flag, RsGroups gs) {
+    int* __restrict__ nan_flag, RsGroups gs, const uint64_t* __restrict__ key_dev, int key_g0) {
   if (gs.n > 0) {   // grouped launch: blockIdx.y is a draw of the stacked batch, with its own rows and Philox key
     const RsGroup& G = gs.g[blockIdx.y];
     const size_t r0 = (size_t)G.seq_lo * L;
     logits += r0 * K; x += r0; x_out += r0;
     log_ratio = G.guided ? log_ratio + (size_t)G.seq_lo * n_slots * K : nullptr;
     rows = G.n_seq * L; seed = G.seed; offset = G.offset; row_offset = G.row_offset;
+  }
+  // Philox key from DEVICE memory (the *_devkey entry points): a launch recorded in a HIP graph is replayed with a new
+  // key without touching its kernel arguments.  Per draw 4 words: seed, first global row, call-offset base, unused.
+  if (key_dev) {
+    const uint64_t* kd = key_dev + 4 * (size_t)(key_g0 + (gs.n > 0 ? (int)blockIdx.y : 0));
+    seed = kd[0]; row_offset = kd[1]; offset += kd[2];
   }
   const int half = (blockIdx.x * 256 + threadIdx.x) >> 5;
   const int k = threadIdx.x & 31;
@@ -209,12 +215,12 @@ __global__ __launch_bounds__(256) void reverse_step_mdlm_kernel(
   }
 }
 
-extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* log_ratio,
-                                      const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
-                                      float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
-                                      int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
-                                      uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
-                                      void* stream) {
+static int reverse_step_mdlm_impl(const float* logits, const int64_t* x, const float* log_ratio,
+                                  const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
+                                  float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
+                                  int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                                  uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
+                                  const uint64_t* key_dev, void* stream) {
   SGPO_REQUIRE(logits && x, "reverse_step_mdlm: null logits/x");
   SGPO_REQUIRE(B > 0 && L > 0 && K > 0 && K <= 32, "reverse_step_mdlm: B=%d L=%d K=%d (K <= 32)", B, L, K);
   SGPO_REQUIRE(mask_index >= 0 && mask_index < K, "reverse_step_mdlm: mask_index %d outside [0,%d)", mask_index, K);
@@ -231,16 +237,38 @@ extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, con
                        (double)rows * (K * 4.0 * ((log_ratio && guide_temp != 0.f && step_mode == SGPO_STEP_SOFT_CG) ? 2 : 1) + 16.0));
   hipLaunchKernelGGL(reverse_step_mdlm_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, logits, x, log_ratio,
                      slot_of_pos, n_slots, rows, L, K, mask_index, move_chance_t, move_chance_s, guide_temp, step_mode,
-                     noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag, RsGroups{});
+                     noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag, RsGroups{}, key_dev, 0);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
+}
+
+extern "C" int sgpo_reverse_step_mdlm(const float* logits, const int64_t* x, const float* log_ratio,
+                                      const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
+                                      float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
+                                      int noise_mode, const float* noise, uint64_t seed, uint64_t offset,
+                                      uint64_t row_offset, int64_t* x_out, float* probs_out, int* nan_flag,
+                                      void* stream) {
+  return reverse_step_mdlm_impl(logits, x, log_ratio, slot_of_pos, n_slots, B, L, K, mask_index, move_chance_t, move_chance_s,
+                                guide_temp, step_mode, noise_mode, noise, seed, offset, row_offset, x_out, probs_out, nan_flag,
+                                nullptr, stream);
+}
+
+extern "C" int sgpo_reverse_step_mdlm_devkey(const float* logits, const int64_t* x, const float* log_ratio,
+                                             const int* slot_of_pos, int n_slots, int B, int L, int K, int mask_index,
+                                             float move_chance_t, float move_chance_s, float guide_temp, int step_mode,
+                                             uint64_t offset, const uint64_t* key_dev, int64_t* x_out, float* probs_out,
+                                             int* nan_flag, void* stream) {
+  SGPO_REQUIRE(key_dev != nullptr, "reverse_step_mdlm_devkey: null key");
+  return reverse_step_mdlm_impl(logits, x, log_ratio, slot_of_pos, n_slots, B, L, K, mask_index, move_chance_t, move_chance_s,
+                                guide_temp, step_mode, SGPO_NOISE_PHILOX, nullptr, 0, offset, 0, x_out, probs_out, nan_flag,
+                                key_dev, stream);
 }
 
 // the classifier-guidance step of several stacked draws in one launch (in-kernel Philox; see mlp.h)
 int launch_reverse_step_mdlm_groups(const RsGroups& gs, int max_seq, const float* logits, const int64_t* x,
                                     const float* log_ratio, const int* slot_of_pos, int n_slots, int L, int K,
                                     int mask_index, float move_chance_t, float move_chance_s, float guide_temp,
-                                    int64_t* x_out, int* nan_flag, hipStream_t stream) {
+                                    int64_t* x_out, int* nan_flag, hipStream_t stream, const uint64_t* key_dev, int key_g0) {
   SGPO_REQUIRE(gs.n > 0 && gs.n <= SGPO_MAX_GROUPS && logits && x && x_out, "reverse_step_mdlm_groups: bad arguments");
   SGPO_REQUIRE(L > 0 && K > 0 && K <= 32 && mask_index >= 0 && mask_index < K, "reverse_step_mdlm_groups: L=%d K=%d mask %d", L, K, mask_index);
   SGPO_REQUIRE(log_ratio == nullptr || slot_of_pos != nullptr || n_slots == L, "reverse_step_mdlm_groups: n_slots must equal L without a slot map");
@@ -252,7 +280,7 @@ int launch_reverse_step_mdlm_groups(const RsGroups& gs, int max_seq, const float
   hipLaunchKernelGGL(reverse_step_mdlm_kernel, dim3(blocks, gs.n), dim3(256), 0, stream, logits, x, log_ratio, slot_of_pos,
                      n_slots, 0, L, K, mask_index, move_chance_t, move_chance_s, guide_temp, SGPO_STEP_SOFT_CG,
                      SGPO_NOISE_PHILOX, (const float*)nullptr, (uint64_t)0, (uint64_t)0, (uint64_t)0, x_out, (float*)nullptr,
-                     nan_flag, gs);
+                     nan_flag, gs, key_dev, key_g0);
   SGPO_CHECK_HIP(hipGetLastError());
   return SGPO_OK;
 }

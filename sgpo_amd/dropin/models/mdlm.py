@@ -116,8 +116,14 @@ class MDLM(GenerativeModel):
         self.injected_noise = deque()   # parity runs: tensors consumed by successive sampling calls
         # one flag word per step of a check window: the sampling loop reads them every NAN_WINDOW steps and still names
         # the first offending step, as the reference raises AT that step (models/mdlm.py:410-411)
+        self.NAN_WINDOW = max(type(self).NAN_WINDOW, int(num_steps))     # a recorded loop checks once, after its last step
         self._nan_flags = torch.zeros(self.NAN_WINDOW, dtype=torch.int32, device=dev)
         self._nan_flag = self._nan_flags[:1]
+        # Opt-in: `Classifier_Guidance_Inpaint.inference` records its whole loop (T - 1 guided steps + projection) into ONE
+        # HIP graph per (batch size, value function, temperature) and replays it with a new Philox key read from device
+        # memory -- for small batches, where the ~70 launches of a step are launch-bound (GPU busy 0.78 at B = 64).
+        # Same tokens as the eager loop, bit for bit.
+        self.use_graphs = False
 
     # ------------------------------------------------------------------ noise bookkeeping
     def reseed(self, seed=None, row_offset=0):
@@ -287,7 +293,8 @@ class MDLM(GenerativeModel):
         return q_t
 
     @torch.no_grad()
-    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False, check=True, step=None):
+    def guided_step(self, x, t, predictor_model=None, guide_temp=0.0, want_probs=False, check=True, step=None,
+                    x_out=None, key_dev=None, key_offset=0, scratch=None):
         """One fused classifier-guidance step (sampling/cls_guidance.py:34-52): denoiser ->
         jump log-ratios -> reverse-step kernel.  Returns the next tokens (and p if asked).
 
@@ -297,6 +304,20 @@ class MDLM(GenerativeModel):
         check still reports the step at which the rates went bad."""
         self._select_nan_slot(step)
         mt, ms, sig_t = self._move_chances(t)
+        if key_dev is not None:
+            # under HIP-graph capture (cls_guidance._GraphedLoop): static buffers from `scratch`, Philox key from device
+            # memory, no host read
+            assert self.diffusion == 'absorbing_state' and not check and not want_probs
+            logits = self._denoise(x, sig_t, out=scratch['logits'])
+            lr = slots = None
+            if predictor_model is not None and guide_temp != 0:
+                vf = predictor_model.hip_value_function()
+                lr = vf.jump_log_ratios(x, float(t), self.S, out=scratch['lr'], mask_index=self.model.mask_index)
+                slots = _slot_map(vf.read_pos, x.shape[1], x.device)
+            xo, _ = rt.reverse_step_mdlm(logits, x, mt, ms, self.model.mask_index, L.STEP_SOFT_CG, log_ratio=lr,
+                                         slot_of_pos=slots, guide_temp=guide_temp, nan_flag=self._nan_flag, x_out=x_out,
+                                         key_dev=key_dev, key_offset=key_offset)
+            return xo
         logits = self._denoise_for_cg(x, sig_t)
         lr = slots = None
         if predictor_model is not None and guide_temp != 0:
@@ -320,7 +341,8 @@ class MDLM(GenerativeModel):
         raise NotImplementedError(f'Diffusion type {self.diffusion} not implemented.')
 
     @torch.no_grad()
-    def guided_step_groups(self, x, t, groups, guide_temp, step=None):
+    def guided_step_groups(self, x, t, groups, guide_temp, step=None, runner=None, slots=None, x_out=None, keys_dev=None,
+                           key_offset=0, logits_out=None):
         """One guided step for SEVERAL independent sampler calls stacked in one batch (Thompson draws of an ensemble,
         iterativeBO.py:204-237): ONE denoiser forward over all rows, then per group its own value function's jump ratios
         and its own reverse step with its own Philox stream.  groups: [(predictor_model, NoiseSource, lo, hi)], rows
@@ -328,6 +350,10 @@ class MDLM(GenerativeModel):
         gets exactly the tokens its own `guided_step` call would have produced."""
         self._select_nan_slot(step)
         mt, ms, sig_t = self._move_chances(t)
+        if keys_dev is not None:     # under HIP-graph capture (cls_guidance._GraphedManyLoop): static buffers, keys from device memory
+            logits = self._denoise(x, sig_t, out=logits_out)
+            return runner.step(logits, x, float(t), mt, ms, self.model.mask_index, guide_temp, slots, self._nan_flag, x_out,
+                               keys_dev=keys_dev, key_offset=key_offset)
         logits = self._denoise_for_cg(x, sig_t)
         x_out = torch.empty_like(x)
         fused = self._fused_groups(groups, x.shape[1]) if self.diffusion == 'absorbing_state' else None

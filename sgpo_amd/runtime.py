@@ -166,6 +166,10 @@ class MlpValueFunction:
         except Exception:
             pass
 
+    def copy_from(self, other):
+        """Overwrite this value function's device tables with `other`'s (same shape), asynchronously on the current stream."""
+        L.check(self.lib.sgpo_mlp_copy(self.handle, other.handle, L.stream_ptr()), 'sgpo_mlp_copy')
+
     def forward(self, x, t=None):
         B, Lq = x.shape
         x = x.contiguous()
@@ -448,19 +452,37 @@ class NoiseSource:
     def __init__(self, seed=42, row_offset=0):
         self.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
         self.row_offset = int(row_offset)
-        self._calls = itertools.count()
+        self.calls = 0
 
     def next_offset(self):
-        return next(self._calls)
+        self.calls += 1
+        return self.calls - 1
+
+    def key_words(self, seq_len):
+        """(seed, first global row, call-offset base, 0): the 4-word device key of the *_devkey entry points for a loop
+        that starts now.  Seeds >= 2^63 are stored by their two's-complement bit pattern (int64 tensors)."""
+        sgn = lambda v: v - (1 << 64) if v >= (1 << 63) else v
+        return [sgn(self.seed), self.row_offset * int(seq_len), self.calls, 0]
 
 
 def reverse_step_mdlm(logits, x, mt, ms, mask_index, step_mode, noise_src=None, noise=None, noise_mode=None,
                       log_ratio=None, slot_of_pos=None, guide_temp=0.0, want_probs=False, nan_flag=None, x_out=None,
-                      L_seq=None):
+                      L_seq=None, key_dev=None, key_offset=0):
     lib = L.load()
     B, Lq, K = logits.shape
     x = x.contiguous()
     logits = logits.contiguous()
+    if key_dev is not None:      # Philox key read from device memory (HIP-graph replay): call index `key_offset` baked in
+        assert noise is None and key_dev.dtype == torch.int64 and key_dev.numel() >= 4 and key_dev.is_cuda
+        probs = torch.empty_like(logits) if want_probs else None
+        if x_out is None:
+            x_out = torch.empty_like(x)
+        n_slots = Lq if log_ratio is None else log_ratio.shape[1]
+        L.check(lib.sgpo_reverse_step_mdlm_devkey(L.ptr(logits), L.ptr(x), L.ptr(log_ratio), L.ptr(slot_of_pos), n_slots, B, Lq,
+                                                  K, mask_index, float(mt), float(ms), float(guide_temp), step_mode,
+                                                  int(key_offset), L.ptr(key_dev), L.ptr(x_out), L.ptr(probs), L.ptr(nan_flag),
+                                                  L.stream_ptr()), 'sgpo_reverse_step_mdlm_devkey')
+        return x_out, probs
     if noise is not None:
         assert noise.dtype == torch.float32
         noise = noise.to(logits.device).contiguous()    # a host pointer handed to a kernel is a GPU fault
@@ -495,7 +517,7 @@ class GuidedStepGroups:
         assert all(v.read_pos == self.read_pos for v in vfs), 'stacked value functions must read the same positions'
         self.members = (C.c_void_p * n)(*[getattr(g[0].handle, 'value', g[0].handle) if g[0] is not None else None for g in groups])
         self.row_lo = (C.c_int * (n + 1))(*([g[2] for g in groups] + [groups[-1][3]]))
-        self.seeds = (C.c_uint64 * n)(*[g[1].seed for g in groups])
+        self.seeds = (C.c_uint64 * n)(*[g[1].seed if g[1] is not None else 0 for g in groups])
         self.offsets = (C.c_uint64 * n)()
         self.n = n
         self.S = S
@@ -505,10 +527,19 @@ class GuidedStepGroups:
         self.ws = torch.empty(self.ws_bytes + 256, dtype=torch.uint8, device=device)
         self.lr = torch.empty(max(self.lr_bytes, 4), dtype=torch.uint8, device=device)
 
-    def step(self, logits, x, t, mt, ms, mask_index, guide_temp, slot_of_pos, nan_flag, x_out):
+    def step(self, logits, x, t, mt, ms, mask_index, guide_temp, slot_of_pos, nan_flag, x_out, keys_dev=None, key_offset=0):
         B, Lq, K = logits.shape
         assert logits.is_contiguous() and x.is_contiguous() and x_out.is_contiguous()
         assert self.row_lo[0] == 0 and self.row_lo[self.n] == B
+        if keys_dev is not None:     # the draws' Philox keys live in device memory (HIP-graph replay)
+            assert keys_dev.dtype == torch.int64 and keys_dev.numel() >= 4 * self.n and keys_dev.is_cuda
+            base = (self.ws.data_ptr() + 255) & ~255
+            L.check(self.lib.sgpo_guided_step_groups_mdlm_devkey(
+                self.n, self.members, self.row_lo, L.ptr(logits), L.ptr(x), Lq, K, self.S, float(t), int(mask_index), float(mt),
+                float(ms), float(guide_temp), int(key_offset), L.ptr(keys_dev), L.ptr(slot_of_pos), L.ptr(self.lr), self.lr_bytes,
+                C.c_void_p(base), self.ws_bytes, L.ptr(x_out), L.ptr(nan_flag), L.stream_ptr()),
+                'sgpo_guided_step_groups_mdlm_devkey')
+            return x_out
         row_offsets = (C.c_uint64 * self.n)(*[g[1].row_offset * Lq for g in self.groups])
         for i, g in enumerate(self.groups):
             self.offsets[i] = g[1].next_offset()
