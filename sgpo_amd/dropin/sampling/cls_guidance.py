@@ -254,7 +254,7 @@ class Classifier_Guidance_Inpaint(Algo):
         x = self.project(x)
         return [x[lo:hi] for _, _, lo, hi in groups]
 
-    def _generic_step(self, x, t):
+    def _generic_step(self, x, t, want_probs=False):
         """sampling/cls_guidance.py:34-52 for nets without a fused step."""
         from sgpo_amd import runtime as rt
         p = self.net.p_sample(x, t, hard=False)
@@ -267,7 +267,8 @@ class Classifier_Guidance_Inpaint(Algo):
         p = p / p.sum(dim=-1, keepdim=True)
         src = getattr(self.net, 'noise_source', None)
         nz = self.net._next_noise() if hasattr(self.net, '_next_noise') else None
-        return rt.categorical_sample(p, noise_src=src, noise=nz)
+        xo = rt.categorical_sample(p, noise_src=src, noise=nz)
+        return (xo, p) if want_probs else xo
 
 
 # names of the reference module that are outside the sampling hot path -- Classifier_Guidance_Continuous (prior_sample.py:15, configs/algorithm/cls_guidance_continuous.yaml) --

@@ -43,3 +43,16 @@ def golden_noise(g, B, L):
     if not same:
         pytest.skip('this torch build draws another Exp(1) stream than the one the golden was made with')
     return es.view(T - 1, B, L, 31)
+
+
+def golden_noise_d3pm(g, B, L, S=26):
+    """The reference's draws for a Classifier_Guidance_Inpaint run on a D3PM net, redrawn from the stored CPU generator
+    seed: get_start's torch.randint first (models/d3pm.py:39-40), then one (B L, S) fp64 Exp(1) tensor per step
+    (torch.multinomial on fp64 rates).  Verified by the golden's first rows and integer checksum."""
+    T = int(g['T'])
+    torch.manual_seed(int(g['noise_seed']))
+    x0 = torch.randint(0, S, (B, L)).to(torch.long)
+    es = torch.stack([torch.empty(B * L, S, dtype=torch.float64).exponential_(1) for _ in range(T - 1)])
+    if not (torch.equal(es[0, :4], g['es_first']) and int(es.view(torch.int64).sum()) == int(g['es_isum'])):
+        pytest.skip('this torch build draws another Exp(1) stream than the one the golden was made with')
+    return x0, es.view(T - 1, B, L, S)

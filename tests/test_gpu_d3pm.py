@@ -420,3 +420,55 @@ def test_cls_guidance_on_d3pm_generic_step(rt):
     xs = algo.inference(num_samples=8)
     frozen = [l for l in range(Lq) if l not in algo.residues]
     assert xs.shape == (8, Lq) and bool((xs[:, frozen] == ALPHABET.index('M')).all()) and int(xs.max()) < S
+
+
+@pytest.mark.parametrize('tag', ['unguided', 'guided'])
+def test_cls_guidance_on_d3pm_teacher_forced_against_reference_trajectory(rt, tag):
+    """Classifier_Guidance_Inpaint on a D3PM net -- the round-0 data path of pareto.py:48-67 (temperature 0) and the
+    guided form -- walked over the REFERENCE's own 499-step run (golden cg_d3pm_small, written by tools/refgen
+    gen_cg_d3pm; the restatement reproduces it state by state, tests/test_oracle_d3pm.py): at every 6th state and the
+    last 12 the drop-in's step gives the oracle's probabilities within the bf16 logit bound (squared p0: logit_rtol
+    2e-2, as in test_d3pm_dropin_and_daps_loop) and the reference's next tokens wherever the race margin exceeds it."""
+    from conftest import golden_noise_d3pm
+    from models.d3pm import D3PM
+    from oracle import bytenet as obn
+    from oracle import cls_guidance as ocg
+    from oracle import d3pm as od3pm
+    from oracle import mdlm as omdlm
+    from oracle import mlp as omlp
+    from problem.protein import ProteinPredictor
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    from sgpo_amd import weights as W
+    from tf_common import TeacherForced
+    g = load_golden('cg_d3pm_small')
+    B, Lq = g[f'x_{tag}'].shape
+    T, temp = int(g['T']), float(g[f'temp_{tag}'])
+    res1 = [int(r) for r in g['residues']]
+    full = bytes(g['full_seq'].numpy().tolist()).decode()
+    sd = W.bytenet_synthetic_state(seed=int(g['bn_seed']), **BN_DEV_SMALL)
+    net = D3PM('synthetic', Lq, device='cuda:0', state_dict=sd)
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq=full, residues=res1)
+    msd = W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res1))
+    pred = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+    pred.model.load_state_dict(msd)
+    pred.eval()
+    algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred if temp else None, temperature=temp, device='cuda:0')
+    opred = omlp.Predictor(msd, res1) if temp else None
+    Q, Q_bar, sigma = _sched()
+    x0, es = golden_noise_d3pm(g, B, Lq)
+    states = g[f'states_{tag}'].long()
+    assert torch.equal(states[0], x0)
+    timesteps = torch.linspace(T - 1, 1, T - 1, dtype=int)
+    tf = TeacherForced(logit_rtol=2e-2, atol=1e-6)
+    picks = sorted(set(range(0, T - 1, 6)) | set(range(T - 13, T - 1)))
+    for i in picks:
+        t, xs, e = timesteps[i], states[i], es[i]
+        logits = obn.bytenet_forward(sd, xs, torch.tensor([int(t)] * B))
+        q = od3pm.p_sample(logits, xs, int(t), None, Q, Q_bar, sigma, S, hard=False)
+        x_ref, p_ref = ocg.cg_step(q, xs, lambda qm: omdlm.get_guided_rates(opred, xs, t, qm, S, guide_temp=temp)[0], e)
+        if i + 1 < T - 1:
+            assert torch.equal(x_ref, states[i + 1]), f'oracle left the reference trajectory at step {i}'
+        net.injected_noise.append(e)
+        xo, p = algo._generic_step(xs.cuda(), t, want_probs=True)
+        tf.step(i, p.cpu().double(), p_ref, xo.cpu(), x_ref, e, float(logits[..., :S].abs().max()))
+    tf.finish(f'cg_d3pm_small/{tag}')

@@ -13,6 +13,7 @@ from oracle import mlp as omlp
 from sgpo_amd import weights as W
 
 BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
+BN_DEV = dict(n_tokens=31, d_embedding=8, d_model=128, n_layers=3, kernel_size=5)   # the smallest the device kernels take
 S = 26
 
 
@@ -105,3 +106,45 @@ def test_daps_inference_tiny():
 
 
 W_ALPHA = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+
+
+ALPHABET = 'ACDEFGHIKLMNPQRSTVWYBZXJOU-*#@!'
+
+
+def oracle_cg_d3pm(g, tag, stop=None):
+    """The restatement's Classifier_Guidance_Inpaint loop on a D3PM net from the golden's start state and noise:
+    (final projected tokens, states before each step)."""
+    from conftest import golden_noise_d3pm
+    from oracle import cls_guidance as ocg
+    from oracle import mdlm as omdlm
+    Q, Q_bar, sigma = _sched()
+    sd = W.bytenet_synthetic_state(seed=int(g['bn_seed']), **BN_DEV)
+    B, L = g[f'x_{tag}'].shape
+    T, temp = int(g['T']), float(g[f'temp_{tag}'])
+    res = [int(r) for r in g['residues']]
+    pred = omlp.Predictor(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res)), res) if temp else None
+    x, es = golden_noise_d3pm(g, B, L)
+    states = []
+    for i, t in enumerate(torch.linspace(T - 1, 1, T - 1, dtype=int)[:stop]):
+        states.append(x.clone())
+        logits = obn.bytenet_forward(sd, x, torch.tensor([int(t)] * B))
+        q = od3pm.p_sample(logits, x, int(t), None, Q, Q_bar, sigma, S, hard=False)
+        xx = x
+        x, _ = ocg.cg_step(q, x, lambda qm: omdlm.get_guided_rates(pred, xx, t, qm, S, guide_temp=temp)[0], es[i])
+    full = torch.tensor([ALPHABET.index(c) for c in bytes(g['full_seq'].numpy().tolist()).decode()])
+    mask = torch.zeros(L, dtype=torch.int64)
+    mask[[r - 1 for r in res]] = 1
+    return ocg.project(x, mask, full), states
+
+
+@pytest.mark.parametrize('tag', ['unguided', 'guided'])
+def test_cls_guidance_inference_on_d3pm(tag):
+    """Classifier_Guidance_Inpaint.inference on a D3PM net: the round-0 data path of pareto.py:48-67 (temperature 0) and
+    the guided form (models/d3pm.py:109-199 inside sampling/cls_guidance.py:34-52), all 499 steps: the restatement
+    visits the reference's states one by one and reaches its projected result."""
+    g = load_golden('cg_d3pm_small')
+    x, states = oracle_cg_d3pm(g, tag)
+    want = g[f'states_{tag}'].long()
+    for i, s_ in enumerate(states):
+        assert torch.equal(s_, want[i]), f'state before step {i}'
+    assert torch.equal(x, g[f'x_{tag}'])

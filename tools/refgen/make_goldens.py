@@ -425,6 +425,7 @@ def gen_cg_udlm():
 
 
 BN_SMALL = dict(n_tokens=31, d_embedding=8, d_model=64, n_layers=3, kernel_size=5)
+BN_DEV = dict(n_tokens=31, d_embedding=8, d_model=128, n_layers=3, kernel_size=5)
 
 
 def build_ref_d3pm(L, bn_seed=41, bn_cfg=None):
@@ -474,6 +475,37 @@ def gen_d3pm():
         out['tq'] = tq
         out['eq'] = eq
     save('d3pm_small', **out)
+
+
+def gen_cg_d3pm():
+    """The reference's own Classifier_Guidance_Inpaint.inference on a D3PM net -- the round-0 data path of pareto.py:48-67
+    (temperature 0, all 499 steps) and the guided form (models/d3pm.py:109-199 inside sampling/cls_guidance.py:34-52) --
+    around the small ByteNet restatement, on a residue subset.  Stores the state before every step and the projected
+    result; the fp64 Exp(1) draws of torch.multinomial (fp64 rates) are redrawn by the tests from the seed: the
+    reference draws get_start's torch.randint first, then one (B L, S) fp64 exponential_ per step."""
+    from sampling.cls_guidance import Classifier_Guidance_Inpaint
+    B, L, S, noise_seed = 2, 24, 26, 85
+    res = [2, 5, 6, 11, 17, 20]
+    full = CREILOV[:L]
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=full, residues=res))
+    pred, msd = build_ref_mlp(len(res), res, seed=45, full_len=L)
+    out = dict(bn_seed=44, mlp_seed=45, noise_seed=noise_seed, residues=np.array(res), full_seq=np.frombuffer(full.encode(), dtype=np.uint8))
+    for tag, temp in (('unguided', 0.0), ('guided', 0.005)):
+        net, sd = build_ref_d3pm(L, bn_seed=44, bn_cfg=BN_DEV)     # d_model 128: the smallest the device kernels take
+        algo = Classifier_Guidance_Inpaint(net, dc, forward_op=pred if temp else None, temperature=temp, device='cpu')
+        T = net.timestep
+        torch.manual_seed(noise_seed)
+        x0 = torch.randint(0, S, (B, L)).to(torch.long)
+        es = torch.stack([torch.empty(B * L, S, dtype=torch.float64).exponential_(1) for _ in range(T - 1)])
+        states = _record_states(net)
+        torch.manual_seed(noise_seed)
+        with torch.no_grad():
+            x = algo.inference(num_samples=B)
+        assert len(states) == T - 1 and torch.equal(states[0], x0)
+        out.update({f'x_{tag}': x, f'temp_{tag}': temp, f'states_{tag}': torch.stack(states).to(torch.int8)})
+    out['es_isum'] = es.view(torch.int64).sum()          # wrap-around integer sum of the bit patterns: order independent
+    out['es_first'] = es[0, :4]
+    save('cg_d3pm_small', T=T, **out)
 
 
 def gen_d3pm_real():
@@ -1055,7 +1087,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(free_run=gen_free_run, cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(cg_d3pm=gen_cg_d3pm, free_run=gen_free_run, cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
