@@ -260,6 +260,76 @@ def test_mdlm_sample_uncond_teacher_forced(env, name):
     assert int((x == 28).sum()) == 0
 
 
+def test_daps_on_mdlm_teacher_forced_against_reference_calls(env):
+    """DAPS on an MDLM net (sampling/daps.py, self.type == "MDLM") against the reference's own tiny inference
+    (daps_mdlm_small.npz, every call recorded; the restatement replays it bit for bit, tests/test_oracle_d3pm.py).  Each of
+    the reference's calls is replayed on the device from the reference's inputs and draws: hard MDLM.p_sample (tokens
+    wherever the race margin exceeds the bf16 logit bound, carry-over exact), the Metropolis-Hastings chain over 31
+    target states (`sgpo_daps_mh`, bit-exact), MDLM.q_sample (bit-exact).  Then the whole loop through the drop-in API on
+    the same draws: it must land on the reference's result wherever no near-tie was met."""
+    from models.mdlm import MDLM
+    from oracle import dit as odit
+    from oracle import mdlm as omdlm
+    from problem.protein import ProteinPredictor
+    from sampling.daps import DAPS
+    from sgpo_amd import weights as W
+    g = load_golden('daps_mdlm_small')
+    dims = dict(zip(DIM_KEYS, [int(v) for v in g['dims']]))
+    sd = W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
+    B, Lq = g['x'].shape
+    T = int(g['T'])
+    res1 = [int(r) for r in g['residues']]
+    full = bytes(g['full_seq'].numpy().tolist()).decode()
+    cfg = dict(diffusion='absorbing_state', parameterization='subs', time_conditioning=False,
+               model=dict(hidden_size=dims['hidden'], cond_dim=dims['cond_dim'], n_blocks=dims['n_blocks'],
+                          n_heads=dims['n_heads'], length=1024))
+    net = MDLM('synthetic', cfg, None, num_steps=T, seq_len=Lq, device='cuda:0', state_dict=sd)
+    dc = dict(alphabet=ALPHABET, alphabet_size=31, seq_len=Lq, full_seq=full, residues=res1)
+    pred = ProteinPredictor(dc, dict(hidden_dim=64), device='cuda:0')
+    pred.model.load_state_dict(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res1)))
+    pred.eval()
+    algo = DAPS(net, forward_op=pred, num_steps=int(g['num_steps']), ode_steps=int(g['ode_steps']), mh_steps=int(g['mh_steps']),
+                alpha=float(g['alpha']), beta=float(g['beta']), data_config=dc, device='cuda:0')
+    assert algo.type == 'MDLM' and torch.equal(algo.time_steps, g['time_steps'])
+    n_ode = int(g['ode_steps']) - 1
+    tf = TeacherForced(min_checked=0.7)
+    for ip in range(g['p_in'].shape[0]):
+        i, k = divmod(ip, n_ode)
+        xs, t, u = g['p_in'][ip], g['p_t'][ip], g[f'inf_ode_u_{i}'][k]
+        z = odit.dit_forward(sd, xs, torch.zeros(B))
+        q_ref = omdlm.p_sample(sd, xs, t, T, 28, hard=False, log_p_x0=omdlm.subs_parameterization(z, xs, 28))
+        net.injected_noise.append(u)
+        xo = net.p_sample(xs.cuda(), t).cpu()
+        q = net.p_sample(xs.cuda(), t, hard=False).cpu()
+        masked = xs == 28
+        assert torch.equal(xo[~masked], xs[~masked])                          # carry-over
+        if bool(masked.any()):
+            tf.step(ip, q[masked], q_ref[masked], xo[masked], g['p_out'][ip][masked], (1e-10 - (u + 1e-10).log())[masked],
+                    float(z.abs().max()))
+    tf.finish('daps_mdlm_small p_sample calls')
+    for i in range(g['mh_in'].shape[0]):
+        algo.injected_mh.append((g[f'inf_mh_idx_{i}'], g[f'inf_mh_val_{i}'], g[f'inf_mh_u_{i}']))
+        x0 = algo.metropolis_hasting(g['mh_in'][i].cuda(), pred, None, net.sigma(algo.time_steps[i]), steps=algo.mh_steps,
+                                     alpha=algo.alpha).cpu()
+        assert torch.equal(x0, g['mh_out'][i]), f'metropolis_hasting call {i}'
+        torch.testing.assert_close(net.sigma(algo.time_steps[i]).float().cpu(), g['mh_sigma'][i], rtol=1e-6, atol=0)
+    assert bool((g['mh_in'] != g['mh_out']).any())                            # the chains do move
+    for i in range(g['q_in'].shape[0]):
+        net.injected_noise.append(g[f'inf_q_u_{i}'])
+        assert torch.equal(net.q_sample(g['q_in'][i].cuda(), g['q_t'][i]).cpu(), g['q_out'][i])
+    # the whole loop on the reference's draws
+    for i in range(algo.num_steps):
+        for k in range(n_ode):
+            net.injected_noise.append(g[f'inf_ode_u_{i}'][k])
+        algo.injected_mh.append((g[f'inf_mh_idx_{i}'], g[f'inf_mh_val_{i}'], g[f'inf_mh_u_{i}']))
+        if i < algo.num_steps - 1:
+            net.injected_noise.append(g[f'inf_q_u_{i}'])
+    x = algo.inference(num_samples=B, verbose=False).cpu()
+    agree = float((x == g['x']).float().mean())
+    print(f'daps_mdlm_small: whole loop agrees with the reference on {agree:.4f} of the positions')
+    assert agree > 0.9 and not net.injected_noise and not algo.injected_mh
+
+
 def test_shard_invariance_of_full_inference(env):
     """Two emulated ranks (row offsets 0 and B/2, same key) reproduce the single-rank batch bit for bit:
     rows are independent in every kernel and the Philox counters are keyed by the global row."""

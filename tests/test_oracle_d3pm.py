@@ -148,3 +148,47 @@ def test_cls_guidance_inference_on_d3pm(tag):
     for i, s_ in enumerate(states):
         assert torch.equal(s_, want[i]), f'state before step {i}'
     assert torch.equal(x, g[f'x_{tag}'])
+
+
+def test_daps_inference_on_mdlm():
+    """DAPS on an MDLM net (sampling/daps.py, self.type == "MDLM"): the restatement replays the reference's tiny full
+    inference call by call from the recorded draws -- hard MDLM.p_sample (defects D1 repaired, D2 kept), the
+    Metropolis-Hastings chain over 31 target states with sigma from net.sigma(t), MDLM.q_sample -- and reaches its
+    result bit for bit."""
+    from oracle import cls_guidance as ocg
+    from oracle import mdlm as omdlm
+    g = load_golden('daps_mdlm_small')
+    dims = dict(zip(('hidden', 'cond_dim', 'n_blocks', 'n_heads'), [int(v) for v in g['dims']]))
+    sd = W.dit_synthetic_state(seed=int(g['seed']), vocab=31, **dims)
+    B, L = g['x'].shape
+    T, S31 = int(g['T']), 31
+    res1 = [int(r) for r in g['residues']]
+    res0 = [r - 1 for r in res1]
+    pred = omlp.Predictor(W.mlp_synthetic_state(seed=int(g['mlp_seed']), n_residues=len(res1)), res1)
+    ts = odaps.time_steps(T, int(g['num_steps']))
+    assert torch.equal(ts, g['time_steps'])
+    n_ode = int(g['ode_steps']) - 1
+    xt = torch.full((B, L), 28, dtype=torch.int64)
+    ip = 0
+    for i in range(int(g['num_steps'])):
+        inner = torch.linspace(int(ts[i]), 0, int(g['ode_steps']), dtype=int)
+        for k in range(n_ode):
+            assert int(inner[k]) == int(g['p_t'][ip]) and torch.equal(xt, g['p_in'][ip])
+            xt = omdlm.p_sample(sd, xt, inner[k], T, 28, hard=True, u=g[f'inf_ode_u_{i}'][k])
+            assert torch.equal(xt, g['p_out'][ip]), f'p_sample call {ip}'
+            ip += 1
+        sigma = omdlm.total_noise(ts[i] / T)                    # MDLM.sigma (models/mdlm.py:100-102)
+        torch.testing.assert_close(sigma.float(), g['mh_sigma'][i], rtol=1e-6, atol=0)
+        assert torch.equal(xt, g['mh_in'][i])
+        x0 = odaps.metropolis_hasting(xt, pred.log_likelihood, sigma, int(g['mh_steps']), float(g['alpha']), float(g['beta']),
+                                      res0, S31, L, g[f'inf_mh_idx_{i}'], g[f'inf_mh_val_{i}'], g[f'inf_mh_u_{i}'])
+        assert torch.equal(x0, g['mh_out'][i]), f'metropolis_hasting call {i}'
+        if i < int(g['num_steps']) - 1:
+            xt = omdlm.q_sample(x0, ts[i + 1].repeat(B), T, 28, g[f'inf_q_u_{i}'])
+            assert torch.equal(xt, g['q_out'][i])
+        else:
+            xt = x0
+    full = torch.tensor([ALPHABET.index(c) for c in bytes(g['full_seq'].numpy().tolist()).decode()])
+    mask = torch.zeros(L, dtype=torch.int64)
+    mask[res0] = 1
+    assert torch.equal(ocg.project(xt, mask, full), g['x'])

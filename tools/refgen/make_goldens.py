@@ -622,6 +622,64 @@ def gen_daps():
     save('daps_small', **out)
 
 
+def gen_daps_mdlm():
+    """DAPS on an MDLM net (sampling/daps.py with self.type == "MDLM": net.sigma(t) a function, net.S = 31 target states in
+    the proposals, hard MDLM.p_sample in the few-step reverse pass -- defect D1 repaired, defect D2 as is), a tiny full
+    inference of the reference.  Records the inputs, the draws and the output of EVERY net.p_sample, metropolis_hasting
+    and net.q_sample call in call order, so that each can be replayed on its own (teacher forcing)."""
+    from sampling.daps import DAPS
+    B, L, T, S = 2, 24, 16, 31
+    residues_1idx = [2, 5, 6, 11, 17, 20]
+    net, core, sd = build_ref_mdlm(SMALL, seed=25, L=L, T=T)
+    full = CREILOV[:L]
+    dc = standins.to_attr(dict(alphabet=standins.ALPHABET, alphabet_size=31, seq_len=L, full_seq=full, residues=residues_1idx))
+    pred, msd = build_ref_mlp(len(residues_1idx), residues_1idx, seed=46, full_len=L)
+    algo = DAPS(net, forward_op=pred, num_steps=3, ode_steps=4, mh_steps=25, alpha=4., max_dist=1, beta=1., data_config=dc,
+                device='cpu')     # beta 1: proposals are accepted now and then (beta 1000 freezes the chain at these sigmas)
+    assert algo.type == 'MDLM'
+    n_res = len(algo.residues)
+    # the draws in the order the loop makes them
+    torch.manual_seed(92)
+    rec = {}
+    for i in range(algo.num_steps):
+        rec[f'ode_u_{i}'] = torch.stack([torch.rand(B, L, S) for _ in range(algo.ode_steps - 1)])
+        a, b, c = [], [], []
+        for _ in range(algo.mh_steps):
+            a.append(torch.randint(n_res, (B,)))
+            b.append(torch.randint(S, (B,)))
+            c.append(torch.rand(B))
+        rec[f'mh_idx_{i}'], rec[f'mh_val_{i}'], rec[f'mh_u_{i}'] = torch.stack(a), torch.stack(b), torch.stack(c)
+        if i < algo.num_steps - 1:
+            rec[f'q_u_{i}'] = torch.rand(B, L)
+    calls = {'p_in': [], 'p_t': [], 'p_out': [], 'mh_in': [], 'mh_sigma': [], 'mh_out': [], 'q_in': [], 'q_t': [], 'q_out': []}
+    p_orig, mh_orig, q_orig = net.p_sample, algo.metropolis_hasting, net.q_sample
+
+    def p_spy(x, t, *a_, **k_):
+        o = p_orig(x, t, *a_, **k_)
+        calls['p_in'].append(x.clone()); calls['p_t'].append(int(t)); calls['p_out'].append(o.clone())
+        return o
+
+    def mh_spy(x0hat, op, y, sigma, **k_):
+        o = mh_orig(x0hat, op, y, sigma, **k_)
+        calls['mh_in'].append(x0hat.clone()); calls['mh_sigma'].append(torch.as_tensor(sigma).reshape(())); calls['mh_out'].append(o.clone())
+        return o
+
+    def q_spy(x, t):
+        o = q_orig(x, t)
+        calls['q_in'].append(x.clone()); calls['q_t'].append(t.clone()); calls['q_out'].append(o.clone())
+        return o
+    net.p_sample, algo.metropolis_hasting, net.q_sample = p_spy, mh_spy, q_spy
+    torch.manual_seed(92)
+    with torch.no_grad():
+        xf = algo.inference(num_samples=B, verbose=False)
+    assert len(calls['p_in']) == algo.num_steps * (algo.ode_steps - 1) and len(calls['mh_in']) == algo.num_steps
+    out = {'inf_' + k: v for k, v in rec.items()}
+    out.update({k: torch.stack([torch.as_tensor(v) for v in vs]) for k, vs in calls.items()})
+    save('daps_mdlm_small', seed=25, mlp_seed=46, dims=np.array(list(SMALL.values())), T=T, residues=np.array(residues_1idx),
+         full_seq=np.frombuffer(full.encode(), dtype=np.uint8), num_steps=3, ode_steps=4, mh_steps=25, alpha=4., beta=1.,
+         time_steps=algo.time_steps, x=xf, **out)
+
+
 def gen_nos():
     """MDLM._nos_denoise (models/mdlm.py:184-338) with the reference DITClassifier head
     (dit.py:420-515, x_emb path: mean-pool + Linear(hidden, 1))."""
@@ -1087,7 +1145,7 @@ def gen_train():
     save('train_mlp', **out)
 
 
-GENS = dict(cg_d3pm=gen_cg_d3pm, free_run=gen_free_run, cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
+GENS = dict(daps_mdlm=gen_daps_mdlm, cg_d3pm=gen_cg_d3pm, free_run=gen_free_run, cg_udlm=gen_cg_udlm, tag=gen_tag, train=gen_train, acquire=gen_acquire, oracle_ens=gen_oracle_ens, dit=gen_dit, mdlm=gen_mdlm, mdlm_sample=gen_mdlm_sample, mlp=gen_mlp, cg=gen_cg, cg_real=gen_cg_real, cg_trpb=gen_cg_trpb, cg_cfg1=gen_cg_cfg1, d3pm=gen_d3pm, d3pm_real=gen_d3pm_real, daps=gen_daps, nos=gen_nos)
 
 if __name__ == '__main__':
     ap = argparse.ArgumentParser()
