@@ -369,6 +369,9 @@ int sgpo_daps_mh(sgpo_mlp* m, const int64_t* x0hat, int N, int L, int S, const i
 /* ---- test / bench access to the building blocks ----------------------------------- */
 /* C[M][N] (fp32) = A[M][K] (bf16) * W[N][K]^T (bf16) through the MFMA GEMM kernel. */
 int sgpo_gemm_bf16(const void* A, const void* W, float* C, int M, int N, int K, void* stream);
+/* test / bench access to the two-workgroups-per-CU GEMM (gemm_q.hip): C bf16 [M][N] = epi(A W^T + bias), A [M][K] and
+ * W [N][K] bf16, bias [N] fp32 or NULL; epi 0 = bias only, 3 = tanh-GELU (the fc1 epilogue of dit.py:302-321). */
+int sgpo_gemm_q_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int epi, void* stream);
 int sgpo_f32_to_bf16(const float* src, void* dst, size_t n, void* stream);
 
 /* ---- per-kernel timing (HIP events on the launch stream; bench.py's roofline leg) -----

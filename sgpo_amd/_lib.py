@@ -54,6 +54,7 @@ SIGNATURES = {
                                           _vp, _sz, _vp, _vp, _vp]),
     'sgpo_guided_step_groups_mdlm_devkey': (_i, [_i, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _f, _f, _f, _u64, _vp, _vp, _vp, _sz,
                                                  _vp, _sz, _vp, _vp, _vp]),
+    'sgpo_gemm_q_bf16': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'sgpo_guidance_noalloc_max_bytes': (_sz, []),
     'sgpo_guidance_ratio_mlp_absorbing_noalloc': (_i, [_vp, _vp, _f, _i, _i, _i, _i, _vp, _vp]),
     'sgpo_fitness_create': (_i, [_vp, _sz, _i, _i, _i, C.POINTER(_vp)]),

@@ -64,6 +64,18 @@ __global__ void copy_f32_kernel(const float* __restrict__ src, float* __restrict
   for (; i < n; i += stride) dst[i] = src[i];
 }
 
+int launch_gemm_q(const GemmParams& p, int epi, hipStream_t stream);
+// test / bench access to the two-workgroups-per-CU GEMM (gemm_q.hip): C bf16 [M][N] = epi(A W^T + bias), epi 0 = bias, 3 = gelu(tanh)
+extern "C" int sgpo_gemm_q_bf16(const void* A, const void* W, const float* bias, void* C, int M, int N, int K, int epi, void* stream) {
+  SGPO_REQUIRE(A && W && C && M > 0 && N > 0 && K > 0, "gemm_q_bf16: bad arguments");
+  GemmParams g = {};
+  g.A = (const bf16_t*)A; g.W = (const bf16_t*)W; g.C = C; g.bias = bias; g.M = M; g.N = N; g.K = K;
+  g.lda = K; g.ldw = K; g.ldc = N; g.L = M; g.B = 1;
+  const int rc = launch_gemm_q(g, epi, (hipStream_t)stream);
+  if (rc == SGPO_ERR_UNSUPPORTED) sgpo_set_error("gemm_q_bf16: shape M=%d N=%d K=%d epi=%d not supported", M, N, K, epi);
+  return rc;
+}
+
 extern "C" int sgpo_gemm_bf16(const void* A, const void* W, float* C, int M, int N, int K, void* stream) {
   GemmParams p = {};
   p.A = (const bf16_t*)A; p.W = (const bf16_t*)W; p.C = C;
