@@ -145,40 +145,55 @@ __global__ __launch_bounds__(256) void ln_gelu_kernel(const float* __restrict__ 
 // H = 512 in the arithmetic of the fused GEMM epilogue (gemm_p.hip, EPI_LN_GELU), operation for operation, so that a
 // batch below the fused kernel's row threshold (GEMM + this pass) gives the bits of a batch above it: a rank's shard of
 // 32 sequences must reproduce the rows of the 64-sequence call.  The epilogue's order: the row is cut
-// into eight 64-column segments (its eight waves); in a segment, "lane half" h owns the quads at columns
-// 32 nt + 8 g + 4 h (nt < 2, g < 4): quad sums accumulated over (nt, g), the two halves added, / 64 -> mean_s; squared
-// deviations from mean_s as one fma chain over (nt, g, q), the halves added -> M2_s; the eight (mean_s, M2_s) combined
-// in segment order (Chan et al.); then fma(((v - mean) rstd), w, b), Abramowitz-Stegun GELU, bf16.
-// Here 16 lanes take a row (lane = 2 segment + half), four rows per wave.
+// into eight 64-column segments (its eight waves); in a segment, lane group e4 < 4 owns the quads at columns
+// 32 nt + 16 nh + 4 e4 (nt < 2, nh < 2): quad sums accumulated over (nt, nh), the groups added as (0 + 2) + (1 + 3), / 64 ->
+// mean_s; squared deviations from mean_s as one fma chain over (nt, nh, q), the groups added the same way -> M2_s; the
+// eight (mean_s, M2_s) combined in segment order (Chan et al.); then fma(((v - mean) rstd), w, b), Abramowitz-Stegun
+// GELU, bf16.  Here 16 lanes take a row (lane = 2 segment + h, holding groups e4 = h and h + 2), four rows per wave.
 __global__ __launch_bounds__(256) void ln_gelu_row512_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                              const float* __restrict__ b, bf16_t* __restrict__ out, int M) {
   const int lane = threadIdx.x & 63;
   int row = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const bool live = row < M;
   if (!live) row = M - 1;                       // keep the shuffles whole; nothing is stored
-  const int seg = (lane & 15) >> 1, lh = lane & 1;
-  const float* xr = x + (size_t)row * 512 + seg * 64 + 4 * lh;
-  float4 v[2][4];
+  const int seg = (lane & 15) >> 1, h = lane & 1;
+  const float* xr = x + (size_t)row * 512 + seg * 64 + 4 * h;
+  float4 v[2][2][2];   // [e: group h / h + 2][nt][nh]
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) v[nt][g] = *reinterpret_cast<const float4*>(xr + nt * 32 + 8 * g);
-  float mean = 0.f;
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+      for (int nh = 0; nh < 2; ++nh) v[e][nt][nh] = *reinterpret_cast<const float4*>(xr + 8 * e + nt * 32 + 16 * nh);
+  float pm2[2];
 #pragma unroll
-    for (int g = 0; g < 4; ++g) mean = rn_add(mean, rn_add(rn_add(v[nt][g].x, v[nt][g].y), rn_add(v[nt][g].z, v[nt][g].w)));
-  mean = rn_mul(rn_add(mean, __shfl_xor(mean, 1)), 1.0f / 64.0f);
-  float sq = 0.f;
+  for (int e = 0; e < 2; ++e) {
+    float a = 0.f;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+    for (int nt = 0; nt < 2; ++nt)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const float e[4] = {v[nt][g].x, v[nt][g].y, v[nt][g].z, v[nt][g].w};
+      for (int nh = 0; nh < 2; ++nh)
+        a = rn_add(a, rn_add(rn_add(v[e][nt][nh].x, v[e][nt][nh].y), rn_add(v[e][nt][nh].z, v[e][nt][nh].w)));
+    pm2[e] = a;
+  }
+  float t = rn_add(pm2[0], pm2[1]);                                         // group h + group h + 2
+  float mean = rn_mul(rn_add(__shfl(t, lane & ~1), __shfl(t, lane | 1)), 1.0f / 64.0f);   // (0 + 2) + (1 + 3)
+  float ps2[2];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) { const float d = e[q] - mean; sq = fmaf(d, d, sq); }
-    }
-  sq = rn_add(sq, __shfl_xor(sq, 1));
+  for (int e = 0; e < 2; ++e) {
+    float sq = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const float el[4] = {v[e][nt][nh].x, v[e][nt][nh].y, v[e][nt][nh].z, v[e][nt][nh].w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float d = el[q] - mean; sq = fmaf(d, d, sq); }
+      }
+    ps2[e] = sq;
+  }
+  t = rn_add(ps2[0], ps2[1]);
+  const float sq = rn_add(__shfl(t, lane & ~1), __shfl(t, lane | 1));
   float ms = 0.f, m2 = 0.f, pm[8];
 #pragma unroll
   for (int s8 = 0; s8 < 8; ++s8) {
@@ -194,21 +209,24 @@ __global__ __launch_bounds__(256) void ln_gelu_row512_kernel(const float* __rest
   const float rstd = rsqrtf(fmaf(m2, 1.0f / 512.0f, 1e-5f));
   if (!live) return;
 #pragma unroll
-  for (int nt = 0; nt < 2; ++nt)
+  for (int e = 0; e < 2; ++e)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int col = seg * 64 + nt * 32 + 8 * g + 4 * lh;
-      const float4 ww = *reinterpret_cast<const float4*>(w + col);
-      const float4 bb = *reinterpret_cast<const float4*>(b + col);
-      const float o0 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].x - mu, rstd), ww.x, bb.x));
-      const float o1 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].y - mu, rstd), ww.y, bb.y));
-      const float o2 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].z - mu, rstd), ww.z, bb.z));
-      const float o3 = epi_gelu_erf_fast(fmaf(rn_mul(v[nt][g].w - mu, rstd), ww.w, bb.w));
-      uint2 pk;
-      pk.x = pack_bf16x2(o0, o1);
-      pk.y = pack_bf16x2(o2, o3);
-      *reinterpret_cast<uint2*>(out + (size_t)row * 512 + col) = pk;
-    }
+    for (int nt = 0; nt < 2; ++nt)
+#pragma unroll
+      for (int nh = 0; nh < 2; ++nh) {
+        const int col = seg * 64 + nt * 32 + 16 * nh + 8 * e + 4 * h;
+        const float4 ww = *reinterpret_cast<const float4*>(w + col);
+        const float4 bb = *reinterpret_cast<const float4*>(b + col);
+        const float4 vv = v[e][nt][nh];
+        const float o0 = epi_gelu_erf_fast(fmaf(rn_mul(vv.x - mu, rstd), ww.x, bb.x));
+        const float o1 = epi_gelu_erf_fast(fmaf(rn_mul(vv.y - mu, rstd), ww.y, bb.y));
+        const float o2 = epi_gelu_erf_fast(fmaf(rn_mul(vv.z - mu, rstd), ww.z, bb.z));
+        const float o3 = epi_gelu_erf_fast(fmaf(rn_mul(vv.w - mu, rstd), ww.w, bb.w));
+        uint2 pk;
+        pk.x = pack_bf16x2(o0, o1);
+        pk.y = pack_bf16x2(o2, o3);
+        *reinterpret_cast<uint2*>(out + (size_t)row * 512 + col) = pk;
+      }
 }
 __global__ __launch_bounds__(256) void ln_gelu_generic_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                               const float* __restrict__ b, bf16_t* __restrict__ out, int M,

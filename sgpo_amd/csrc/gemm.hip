@@ -81,27 +81,22 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
     }
   };
 
-  f32x16 acc[MTW][2];
+  // products: v_mfma_f32_16x16x32_bf16 (the shape of the persistent kernel, gemm_p.hip: same K order -- two 32-wide slices per
+  // stage -- and the same instruction, so the two kernels give the same bits).  A 32x32 block is four 16x16 products:
+  // acc[a][b][2 mh + nh][q] = D[m local = a*32 + 16 mh + 4 l4 + q][n local = b*32 + 16 nh + l16]
+  f32x4 acc[MTW][2][4];
 #pragma unroll
   for (int a = 0; a < MTW; ++a)
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+      for (int r = 0; r < 4; ++r) acc[a][b][r] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // fragment read offsets (bytes inside a tile): row*128 + ((c ^ ((row>>1)&7)) * 16)
-  const int lr = lane & 31, lh = lane >> 5;
-  int a_off[MTW], b_off[2], a_sw[MTW], b_sw[2];
-#pragma unroll
-  for (int t = 0; t < MTW; ++t) {
-    const int ra = wr * 32 * MTW + t * 32 + lr;
-    a_off[t] = ra * 128; a_sw[t] = (ra >> 1) & 7;
-  }
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {
-    const int rb = wc * 64 + t * 32 + lr;
-    b_off[t] = rb * 128; b_sw[t] = (rb >> 1) & 7;
-  }
+  // fragment read offsets (bytes inside a tile): row*128 + ((c ^ ((row>>1)&7)) * 16); lane (l16, l4) reads the 8 k of chunk
+  // 4 ks + l4 of row l16 of a 16-row group (rows 16 h + l16 of a 32-row block share the swizzle term)
+  const int l16 = lane & 15, l4 = lane >> 4;
+  const int sw = (l16 >> 1) & 7;
+  const int a_off = (wr * 32 * MTW + l16) * 128, b_off = (wc * 64 + l16) * 128;
 
   const int nk = p.K / BK;
 #pragma unroll
@@ -124,39 +119,48 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmParams p, GemmSeg sg
     const char* abase = smem + slot * STAGE_BYTES;
     const char* bbase = abase + A_TILE_BYTES;
 #pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int c = kk * 2 + lh;
-      bf16x8 af[MTW], bfr[2];
+    for (int ks = 0; ks < 2; ++ks) {
+      const int c = ((ks * 4 + l4) ^ sw) << 4;
+      bf16x8 af[MTW][2], bfr[2][2];
 #pragma unroll
-      for (int t = 0; t < MTW; ++t) af[t] = *reinterpret_cast<const bf16x8*>(abase + a_off[t] + ((c ^ a_sw[t]) << 4));
+      for (int t = 0; t < MTW; ++t)
 #pragma unroll
-      for (int t = 0; t < 2; ++t) bfr[t] = *reinterpret_cast<const bf16x8*>(bbase + b_off[t] + ((c ^ b_sw[t]) << 4));
+        for (int h = 0; h < 2; ++h) af[t][h] = *reinterpret_cast<const bf16x8*>(abase + a_off + (t * 32 + h * 16) * 128 + c);
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) bfr[t][h] = *reinterpret_cast<const bf16x8*>(bbase + b_off + (t * 32 + h * 16) * 128 + c);
 #pragma unroll
       for (int a = 0; a < MTW; ++a)
 #pragma unroll
         for (int b = 0; b < 2; ++b)
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[a], bfr[b], acc[a][b], 0, 0, 0);
+#pragma unroll
+          for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh)
+              acc[a][b][2 * mh + nh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[a][mh], bfr[b][nh], acc[a][b][2 * mh + nh], 0, 0, 0);
     }
     if (++slot == NST) slot = 0;
   }
 
   // ---------------------------------------------------------------- epilogue
-  // D[row = (r&3) + 8*(r>>2) + 4*lh][col = lr]
   const int ncol0 = n0 + wc * 64;
 #pragma unroll
   for (int mt = 0; mt < MTW; ++mt) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int m = m0 + wr * 32 * MTW + mt * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+      const int mh = r >> 3, nh = (r >> 2) & 1, q = r & 3;
+      const int m = m0 + wr * 32 * MTW + mt * 32 + 16 * mh + 4 * l4 + q;
       if (m >= p.M) continue;
-      float v0 = acc[mt][0][r], v1 = acc[mt][1][r];
-      const int na = ncol0 + lr, nb = ncol0 + 32 + lr;
+      float v0 = acc[mt][0][2 * mh + nh][q], v1 = acc[mt][1][2 * mh + nh][q];
+      const int lc = 16 * nh + l16;   // column inside the 32-column block
+      const int na = ncol0 + lc, nb = ncol0 + 32 + lc;
       if constexpr (EPI == EPI_QKV_ROPE) {
         bf16_t* C = reinterpret_cast<bf16_t*>(p.C);
         if (ncol0 < p.rope_cols) {  // wave-uniform: a whole head (64 cols) of q or k
           const int pos = m % p.L;
-          const float cs = p.rope_cos[pos * (p.head_dim / 2) + lr];
-          const float sn = p.rope_sin[pos * (p.head_dim / 2) + lr];
+          const float cs = p.rope_cos[pos * (p.head_dim / 2) + lc];
+          const float sn = p.rope_sin[pos * (p.head_dim / 2) + lc];
           float o0, o1;
           epi_rope(v0, v1, cs, sn, o0, o1);
           v0 = o0; v1 = o1;

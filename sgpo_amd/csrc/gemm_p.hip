@@ -123,6 +123,25 @@ __device__ __forceinline__ void lds_read4(f32x4_t (&o)[4], uint32_t a0, uint32_t
       : "v"(a0), "v"(a1), "v"(a2), "v"(a3)
       : "memory");
 }
+// 2 x 16 B at two addresses / at addr and addr + 64
+__device__ __forceinline__ void lds_read2(f32x4_t (&o)[2], uint32_t a0, uint32_t a1) {
+  asm volatile(
+      "ds_read_b128 %0, %2\n\t"
+      "ds_read_b128 %1, %3\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1])
+      : "v"(a0), "v"(a1)
+      : "memory");
+}
+__device__ __forceinline__ void lds_read2x16(f32x4_t (&o)[2], uint32_t addr) {
+  asm volatile(
+      "ds_read_b128 %0, %2\n\t"
+      "ds_read_b128 %1, %2 offset:64\n\t"
+      "s_waitcnt lgkmcnt(0)"
+      : "=&v"(o[0]), "=&v"(o[1])
+      : "v"(addr)
+      : "memory");
+}
 __device__ __forceinline__ void lds_write16(uint32_t addr, f32x4_t v) {
   asm volatile("ds_write_b128 %0, %1" ::"v"(addr), "v"(v) : "memory");
 }
@@ -198,6 +217,13 @@ __device__ __forceinline__ float half_pair_sum(float x) {
   return __uint_as_float(r[0]) + __uint_as_float(r[1]);
 }
 
+// x summed over the four lanes l, l ^ 16, l ^ 32, l ^ 48 as (x[l4 = 0] + x[2]) + (x[1] + x[3]), the same bits in all four
+__device__ __forceinline__ float quad_lane_sum(float x) {
+  const float t = half_pair_sum(x);
+  const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(t), __float_as_uint(t), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 template <int EPI, bool CONV, typename CFG, bool ROPE_LDS>
 __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, const bf16_t* zero16, int ntm, int ntn,
                                                      int grouped, int flags, int dbg) {
@@ -234,7 +260,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  const int lr = lane & 31, lh = lane >> 5;
+
   const int nk = p.K / BK;
   float* auxf = reinterpret_cast<float*>(smem + NST * STAGE);
   const bool exact = CAN_EXACT && (flags & PF_EXACT) && nk > D;
@@ -365,18 +391,25 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     }
   };
 
-  // ---- fragment addressing inside a slot: the swizzle term is the same for every mt / nt of a lane
-  const int sw = (CH == 8) ? (lr >> 1) & 7 : (lr >> 2) & 3;
-  const int a_lane = (wm * MT * 32 + lr) * ROWB;
-  const int b_lane = A_BYTES + (wn * NT * 32 + lr) * ROWB;
-  int cx[KK];
+  // ---- fragment addressing inside a slot.  The products are v_mfma_f32_16x16x32_bf16 (MI355X_MICROARCH.md, DVFS item 7:
+  // the chip holds a higher clock on this shape than on 32x32x16 at equal cycles per flop; the K loops measured 6-8 % shorter,
+  // profiles/r3/r3f_gemm_kloop_pricing.txt).  A phase is one 32-wide K slice: lane (l16 = lane & 15, l4 = lane >> 4) reads
+  // the 8 consecutive k of chunk ph*4 + l4 of row l16 of a 16-row group -- one ds_read_b128 per 16 rows, the same count
+  // and the same bank pattern (16 consecutive rows per 16 lanes) as the 32-row fragments of the other shape.
+  static_assert(CH == 8 && KK == 4 && PH == 2, "one 32-wide K slice per phase, 128-B rows");
+  const int l16 = lane & 15, l4 = lane >> 4;
+  const int a_lane = (wm * MT * 32 + l16) * ROWB;
+  const int b_lane = A_BYTES + (wn * NT * 32 + l16) * ROWB;
+  int cx[PH];   // rows 16 h + l16 of any 32-row block share the swizzle term
 #pragma unroll
-  for (int kk = 0; kk < KK; ++kk) cx[kk] = ((kk * 2 + lh) ^ sw) << 4;
+  for (int ph = 0; ph < PH; ++ph) cx[ph] = ((ph * 4 + l4) ^ ((l16 >> 1) & 7)) << 4;
 
-  f32x16 acc[NT][MT];  // D[row = n local][col = m local]
+  // A 32x32 output block is four 16x16 products: acc[nt][mt][2 nh + mh][q] = D[n local = nt*32 + 16 nh + 4 l4 + q][m local =
+  // mt*32 + 16 mh + l16] -- a lane owns TWO rows per block and two column quads of each
+  f32x4_t acc[NT][MT][4];
   float4 res[PRE ? MT * NT * 4 : 1];
 
-  // ---- epilogue of tile (m0, n0): lane owns rows m(mt) and column quads n = nb0 + nt*32 + 8g + 4lh
+  // ---- epilogue of tile (m0, n0): lane owns rows m(mt, mh) and column quads n = nb0 + nt*32 + 16 nh + 4 l4
   // bf16 output block of one mt (32 rows x 64 columns, 4 KiB) goes through LDS so that every store
   // instruction writes 8 whole 128-B lines (lane = 16 B) instead of 8 B in each of 32 lines: the
   // row-per-lane store tail is bound by store instructions x lines touched, not by bytes.  The block
@@ -397,10 +430,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     lds_write8(wbase + (((nt * 4 + g) ^ (lr & 7)) << 4), v);
   };
   // the block image back as whole lines, to global memory
-  auto block_flush = [&](uint32_t h0, uint32_t h1, int m_blk, int nb0, auto full_tag) {
+  auto block_flush = [&](uint32_t h0, uint32_t h1, int m_blk, int nb0, int le, auto full_tag) {   // le = lane (the epilogue's opaque copy)
     constexpr bool FULL = decltype(full_tag)::value;
-    int le = lane;
-    if constexpr (LNG) asm volatile("" : "+v"(le));   // addresses formed here, not kept in registers across the K loop
     const int r8 = le >> 3, c8 = le & 7;
     const uint32_t roff = r8 * 128 + ((c8 ^ r8) << 4);
     u32x4_t o[4];
@@ -416,23 +447,13 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
         __builtin_nontemporal_store(v, reinterpret_cast<u32x4_t*>(cp + (size_t)(i * 8) * p.ldc));   // streamed once: keep L2 for the operand panels
     }
   };
-  auto store_block = [&](const u32x2_t (&pk)[NT][4], int m_blk, int nb0, int fslot, auto full_tag) {
-    const uint32_t h0 = blk_h0(fslot), h1 = blk_h1(fslot, h0);
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) block_put(h0, h1, nt, g, pk[nt][g], lr, lh);
-    block_flush(h0, h1, m_blk, nb0, full_tag);
-  };
-
   // fp32 residual epilogue of the 256x256 tile, one mt block (32 rows x 64 columns, 8 KiB) at a time:
-  // y = gate * (acc + bias) goes through the wave's own pieces of the free slot (as store_block does) and
+  // y = gate * (acc + bias) goes through the wave's own pieces of the free slot (as the bf16 blocks do) and
   // comes back one 16-B chunk per lane, 4 whole 256-B rows per instruction; the residual x is loaded
   // and x + y stored in that layout, so every global access is a run of whole lines.  Image: row r at
   // (r & 15) * 256 in half r >> 4, 16-B chunk c at c ^ (r & 7).
-  auto res_block = [&](int m_blk, int nb0, uint32_t h0, uint32_t h1, auto full_tag) {
+  auto res_block = [&](int m_blk, int nb0, uint32_t h0, uint32_t h1, int r4, int c16, auto full_tag) {   // r4 = lane >> 4, c16 = lane & 15
     constexpr bool FULL = decltype(full_tag)::value;
-    const int r4 = lane >> 4, c16 = lane & 15;
     float* cp = reinterpret_cast<float*>(p.C) + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
     const float* xp = (RES ? p.xin : reinterpret_cast<const float*>(p.C)) + (size_t)(m_blk + r4) * p.ldc + nb0 + c16 * 4;
     f32x4_t xr[HAS_X ? 8 : 1];
@@ -470,71 +491,81 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     constexpr bool FULL = decltype(full_tag)::value;
     const int nb0 = n0 + wn * NT * 32;
     if (!FULL && !(F32OUT && !F32ST) && nb0 >= p.N) return;   // wave-uniform: this wave's 64 columns lie outside N
+    // this lane's place in the 16x16 products (rows 16 mh + e16 of a 32-row block, column quads 16 nh + 4 e4 of a 32-column
+    // block), formed from an opaque copy INSIDE the epilogue: derived from `lane` directly the values are tile-invariant,
+    // get hoisted out of the persistent loop and stay live through the K loop
+    int le = lane;
+    asm volatile("" : "+v"(le));
+    const int e16 = le & 15, e4 = le >> 4, ec = e4 >> 1, eh = e4 & 1;
     if constexpr (EPI == EPI_QKV_ROPE) {
       const bool rope = nb0 < p.rope_cols;  // wave-uniform: the 64 columns are one head of q, k or v
       const int hd2 = p.head_dim / 2;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m_blk = m0 + wm * MT * 32 + mt * 32;
-        const int m = m_blk + lr;
-        const int pos = ((FULL || m < p.M) ? m : 0) % p.L;
-        f32x4_t cs_l[4], sn_l[4];
-        if constexpr (ROPE_LDS) {
-          const uint32_t rb = lds_addr(auxf + pos * 32), key = (pos >> 1) & 7, sb = (uint32_t)p.L * 128;
-          const uint32_t c0 = ((lh + 0) ^ key) << 4, c1 = ((lh + 2) ^ key) << 4, c2 = ((lh + 4) ^ key) << 4,
-                         c3 = ((lh + 6) ^ key) << 4;
-          lds_read4(cs_l, rb + c0, rb + c1, rb + c2, rb + c3);
-          lds_read4(sn_l, rb + sb + c0, rb + sb + c1, rb + sb + c2, rb + sb + c3);
-        }
-        u32x2_t pk[NT][4];
+        const uint32_t h0 = blk_h0(fslot), h1 = blk_h1(fslot, h0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int d = 8 * g + 4 * lh;
-          float a0[4], a1[4];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) { a0[q] = acc[0][mt][4 * g + q]; a1[q] = acc[1][mt][4 * g + q]; }
-          if (rope) {
-            f32x4_t cs, sn;
-            if constexpr (ROPE_LDS) {
-              cs = cs_l[g]; sn = sn_l[g];
-            } else {
-              cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + pos * hd2 + d);
-              sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + pos * hd2 + d);
-            }
-            const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
-#pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              float o0, o1;
-              epi_rope(a0[q], a1[q], c4[q], s4[q], o0, o1);
-              a0[q] = o0; a1[q] = o1;
-            }
+        for (int mh = 0; mh < 2; ++mh) {
+          const int row = mh * 16 + e16;
+          const int m = m_blk + row;
+          const int pos = ((FULL || m < p.M) ? m : 0) % p.L;
+          f32x4_t cs_l[2], sn_l[2];   // table chunks 4 nh + e4 of this position (columns d = 16 nh + 4 e4 of the head's first half)
+          if constexpr (ROPE_LDS) {
+            const uint32_t rb = lds_addr(auxf + pos * 32), key = (pos >> 1) & 7, sb = (uint32_t)p.L * 128;
+            const uint32_t c0 = ((uint32_t)e4 ^ key) << 4, c1 = ((uint32_t)(e4 + 4) ^ key) << 4;
+            lds_read2(cs_l, rb + c0, rb + c1);
+            lds_read2(sn_l, rb + sb + c0, rb + sb + c1);
           }
-          pk[0][g] = pack4(a0[0], a0[1], a0[2], a0[3]);
-          pk[1][g] = pack4(a1[0], a1[1], a1[2], a1[3]);
+#pragma unroll
+          for (int nh = 0; nh < 2; ++nh) {
+            const int d = 16 * nh + 4 * e4;
+            const f32x4_t x0 = acc[0][mt][2 * nh + mh], x1 = acc[1][mt][2 * nh + mh];
+            float a0[4] = {x0.x, x0.y, x0.z, x0.w}, a1[4] = {x1.x, x1.y, x1.z, x1.w};
+            if (rope) {
+              f32x4_t cs, sn;
+              if constexpr (ROPE_LDS) {
+                cs = cs_l[nh]; sn = sn_l[nh];
+              } else {
+                cs = *reinterpret_cast<const f32x4_t*>(p.rope_cos + pos * hd2 + d);
+                sn = *reinterpret_cast<const f32x4_t*>(p.rope_sin + pos * hd2 + d);
+              }
+              const float c4[4] = {cs.x, cs.y, cs.z, cs.w}, s4[4] = {sn.x, sn.y, sn.z, sn.w};
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                float o0, o1;
+                epi_rope(a0[q], a1[q], c4[q], s4[q], o0, o1);
+                a0[q] = o0; a1[q] = o1;
+              }
+            }
+            block_put(h0, h1, 0, 2 * nh + ec, pack4(a0[0], a0[1], a0[2], a0[3]), row, eh);
+            block_put(h0, h1, 1, 2 * nh + ec, pack4(a1[0], a1[1], a1[2], a1[3]), row, eh);
+          }
         }
-        store_block(pk, m_blk, nb0, fslot, full_tag);
+        block_flush(h0, h1, m_blk, nb0, le, full_tag);
         __builtin_amdgcn_sched_barrier(0);   // one block at a time: keeps the epilogue's register peak down
       }
     } else if constexpr (F32OUT && !F32ST) {
       float* C = reinterpret_cast<float*>(p.C);
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m = m0 + wm * MT * 32 + mt * 32 + lr;
-        const bool mok = m < p.M;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mh = 0; mh < 2; ++mh) {
+          const int m = m0 + wm * MT * 32 + mt * 32 + mh * 16 + e16;
+          const bool mok = m < p.M;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+          for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q)
-              if (mok && n + q < p.N) {
-                float o = acc[nt][mt][4 * g + q] + p.bias[n + q];
-                if constexpr (EPI == EPI_ACC_F32) o += C[(size_t)m * p.ldc + n + q];
-                C[(size_t)m * p.ldc + n + q] = o;
-              }
-          }
-      }
+            for (int nh = 0; nh < 2; ++nh) {
+              const int n = nb0 + nt * 32 + 16 * nh + 4 * e4;
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                if (mok && n + q < p.N) {
+                  float o = acc[nt][mt][2 * nh + mh][q] + p.bias[n + q];
+                  if constexpr (EPI == EPI_ACC_F32) o += C[(size_t)m * p.ldc + n + q];
+                  C[(size_t)m * p.ldc + n + q] = o;
+                }
+            }
+        }
     } else if constexpr (RLN) {
       // x_new = x + gate (acc + bias) as in the staged fp32 residual epilogue (same arithmetic, same bits), one 32-row block
       // at a time: y goes through the wave's own pieces of the free slot and comes back transposed (a lane holds the quad
@@ -546,13 +577,8 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       char* fs = smem + fslot * STAGE;
       const uint32_t st_base = lds_addr(fs);          // 2 x [wave][32 rows] (mean_s, M2_s): 4 KiB
       const uint32_t h0 = lds_addr(fs + A_BYTES + (wave * B_PW) * 1024), h1 = h0 + 4096;
-      // every lane-derived value of the epilogue is formed from this opaque copy, inside the epilogue: derived from `lane`
-      // directly they are tile-invariant, get hoisted out of the persistent loop and stay live through the K loop
-      int le = lane;
-      asm volatile("" : "+v"(le));
-      const int lr = le & 31, lh = le >> 5;
-      const uint32_t wbase = ((lr >> 4) ? h1 : h0) + (lr & 15) * 256;
-      const int r4 = le >> 4, c16 = le & 15;
+      const int lr = le & 31;
+      const int r4 = e4, c16 = e16;
       const uint32_t k0 = r4 * 256 + ((c16 ^ r4) << 4), k1 = r4 * 256 + ((c16 ^ (r4 + 4)) << 4);
       const bool per_seq = p.gate_stride != 0;        // wave-uniform: one modulation row per sequence, else one for all
       const int nq = nb0 + c16 * 4;
@@ -560,24 +586,29 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       for (int mt = 0; mt < MT; ++mt) {
         const int m_blk = m0 + mt * 32;
         const uint32_t area = st_base + (mt & 1) * 2048;
-        size_t goff = 0;
-        if (per_seq) {
-          int b = ((FULL || m_blk + lr < p.M) ? m_blk + lr : p.M - 1) / p.L;
-          if (b > p.B - 1) b = p.B - 1;
-          goff = (size_t)b * p.gate_stride;
-        }
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            int n = nb0 + nt * 32 + 8 * g + 4 * lh;
-            asm volatile("" : "+v"(n));   // opaque: the table loads of the four blocks are not merged and kept live
-            const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
-            const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + goff + n);
-            const f32x4_t v = {rn_mul(acc[nt][mt][4 * g + 0] + b4.x, g4.x), rn_mul(acc[nt][mt][4 * g + 1] + b4.y, g4.y),
-                               rn_mul(acc[nt][mt][4 * g + 2] + b4.z, g4.z), rn_mul(acc[nt][mt][4 * g + 3] + b4.w, g4.w)};
-            lds_write16(wbase + (((nt * 8 + 2 * g + lh) ^ (lr & 7)) << 4), v);
+        for (int mh = 0; mh < 2; ++mh) {
+          const int row = mh * 16 + e16;
+          const uint32_t wb = (mh ? h1 : h0) + e16 * 256;
+          size_t goff = 0;
+          if (per_seq) {
+            int b = ((FULL || m_blk + row < p.M) ? m_blk + row : p.M - 1) / p.L;
+            if (b > p.B - 1) b = p.B - 1;
+            goff = (size_t)b * p.gate_stride;
           }
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+              int n = nb0 + nt * 32 + 16 * nh + 4 * e4;
+              asm volatile("" : "+v"(n));   // opaque: the table loads of the blocks are not merged and kept live
+              const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
+              const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + goff + n);
+              const f32x4_t a = acc[nt][mt][2 * nh + mh];
+              const f32x4_t v = {rn_mul(a.x + b4.x, g4.x), rn_mul(a.y + b4.y, g4.y), rn_mul(a.z + b4.z, g4.z), rn_mul(a.w + b4.w, g4.w)};
+              lds_write16(wb + (((nt * 8 + 4 * nh + e4) ^ (e16 & 7)) << 4), v);
+            }
+        }
         float* cp = reinterpret_cast<float*>(p.C) + (size_t)(m_blk + r4) * p.ldc + nq;
         const float* xp = p.xin + (size_t)(m_blk + r4) * p.ldc + nq;
         f32x4_t xs[8];
@@ -643,183 +674,208 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       }
       __builtin_amdgcn_s_barrier();   // every wave has read its last statistics: the slot may be refilled
     } else if constexpr (LNG) {
-      // bias, then LayerNorm over the 512 outputs of each row, affine, exact GELU, bf16.  A lane holds 32 of a row's
-      // values per mt (its partner lane ^ 32 the other 32 of the wave's 64 columns), the other seven waves the rest.
-      // Each wave reduces its 64 columns to (mean_w, M2_w = sum of squared deviations from mean_w); the eight partials
-      // are combined exactly (Chan et al.): mean = avg(mean_w), M2 = sum M2_w + 64 sum (mean_w - mean)^2 -- as accurate
-      // as the two-pass form of ln_gelu_kernel, one exchange.  Partials live in the A region of the free slot
-      // ([wave][mt][row] float2, 8 KiB): written, barrier, read by every wave, barrier (the next prefetch overwrites
-      // it).  Both wave groups run their epilogue in the same barrier interval, so the two extra barriers pair up.
+      // bias, then LayerNorm over the 512 outputs of each row, affine, exact GELU, bf16.  A lane holds 16 values of each of
+      // its 8 rows (mt, mh): the quads at columns 32 nt + 16 nh + 4 e4 of the wave's 64; lanes e4 = 0..3 hold the rest of the
+      // segment, the other seven waves the rest of the row.  Each wave reduces its 64 columns to (mean_w, M2_w = sum of
+      // squared deviations from mean_w): per lane the quad sums accumulated over (nt, nh), then (e4: (0 + 2) + (1 + 3)); the
+      // eight partials are combined exactly (Chan et al.): mean = avg(mean_w), M2 = sum M2_w + 64 sum (mean_w - mean)^2 -- as
+      // accurate as the two-pass form, one exchange.  Partials live in the A region of the free slot ([wave][mt][row] float2,
+      // 8 KiB): written, barrier, read by every wave, barrier (the next prefetch overwrites it).  Both wave groups run
+      // their epilogue in the same barrier interval, so the two extra barriers pair up.  ln_gelu_row512_kernel (bytenet.hip)
+      // repeats this arithmetic operation for operation.
       const uint32_t st_base = lds_addr(smem + fslot * STAGE);
       // (the accumulators are only read: acc + bias is formed again in each of the three passes, from L1/L2-resident
       //  bias quads -- updating them in place made the register allocator keep a second copy and spill)
-      float mean[MT], rstd[MT];
+      float mean[MT][2], rstd[MT][2];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) mean[mt] = 0.f;
+      for (int mt = 0; mt < MT; ++mt) { mean[mt][0] = 0.f; mean[mt][1] = 0.f; }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+        for (int nh = 0; nh < 2; ++nh) {
+          int n = nb0 + nt * 32 + 16 * nh + 4 * e4;
           asm volatile("" : "+v"(n));   // opaque: identical loads of the three passes are not merged (and kept live)
           const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            mean[mt] += ((acc[nt][mt][4 * g + 0] + b4.x) + (acc[nt][mt][4 * g + 1] + b4.y)) +
-                        ((acc[nt][mt][4 * g + 2] + b4.z) + (acc[nt][mt][4 * g + 3] + b4.w));
+#pragma unroll
+            for (int mh = 0; mh < 2; ++mh) {
+              const f32x4_t a = acc[nt][mt][2 * nh + mh];
+              mean[mt][mh] += ((a.x + b4.x) + (a.y + b4.y)) + ((a.z + b4.z) + (a.w + b4.w));
+            }
         }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) { mean[mt] = half_pair_sum(mean[mt]) * (1.0f / 64.0f); rstd[mt] = 0.f; }
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) { mean[mt][mh] = quad_lane_sum(mean[mt][mh]) * (1.0f / 64.0f); rstd[mt][mh] = 0.f; }
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+        for (int nh = 0; nh < 2; ++nh) {
+          int n = nb0 + nt * 32 + 16 * nh + 4 * e4;
           asm volatile("" : "+v"(n));
           const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
           const float bv[4] = {b4.x, b4.y, b4.z, b4.w};
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const float d = (acc[nt][mt][4 * g + q] + bv[q]) - mean[mt];
-              rstd[mt] = fmaf(d, d, rstd[mt]);
-            }
+            for (int mh = 0; mh < 2; ++mh)
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                const float d = (acc[nt][mt][2 * nh + mh][q] + bv[q]) - mean[mt][mh];
+                rstd[mt][mh] = fmaf(d, d, rstd[mt][mh]);
+              }
         }
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const float sq = half_pair_sum(rstd[mt]);
-        if (lh == 0) {
-          u32x2_t w2;
-          w2.x = __float_as_uint(mean[mt]); w2.y = __float_as_uint(sq);
-          lds_write8(st_base + (((wave * MT + mt) * 32 + lr) << 3), w2);
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+          const float sq = quad_lane_sum(rstd[mt][mh]);
+          if (e4 == 0) {
+            u32x2_t w2;
+            w2.x = __float_as_uint(mean[mt][mh]); w2.y = __float_as_uint(sq);
+            lds_write8(st_base + (((wave * MT + mt) * 32 + mh * 16 + e16) << 3), w2);
+          }
         }
-      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        f32x2_vt pw[8];
-        lds_read8x8(pw, st_base + ((mt * 32 + lr) << 3));
-        float ms = 0.f, m2 = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { ms += pw[w].x; m2 += pw[w].y; }
-        const float mu = ms * 0.125f;
-        float dv = 0.f;
-#pragma unroll
-        for (int w = 0; w < 8; ++w) { const float d = pw[w].x - mu; dv = fmaf(d, d, dv); }
-        m2 = fmaf(64.0f, dv, m2);
-        mean[mt] = mu;
-        rstd[mt] = rsqrtf(fmaf(m2, 1.0f / (float)BN, p.ln_eps));   // explicit: ln_gelu_row512_kernel (bytenet.hip) mirrors this
-      }
-      __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
+      // (the eight partials of a row are combined where the row is normalised, block by block: only two rows' (mean, rstd)
+      //  are live at a time instead of eight)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m_blk = m0 + mt * 32;
         const uint32_t h0 = blk_h0(fslot), h1 = blk_h1(fslot, h0);
+        float mu2[2], rs2[2];
+#pragma unroll
+        for (int mh = 0; mh < 2; ++mh) {
+          f32x2_vt pw[8];
+          lds_read8x8(pw, st_base + ((mt * 32 + mh * 16 + e16) << 3));
+          float ms = 0.f, m2 = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) { ms += pw[w].x; m2 += pw[w].y; }
+          const float mu = ms * 0.125f;
+          float dv = 0.f;
+#pragma unroll
+          for (int w = 0; w < 8; ++w) { const float d = pw[w].x - mu; dv = fmaf(d, d, dv); }
+          m2 = fmaf(64.0f, dv, m2);
+          mu2[mh] = mu;
+          rs2[mh] = rsqrtf(fmaf(m2, 1.0f / (float)BN, p.ln_eps));   // explicit: ln_gelu_row512_kernel (bytenet.hip) mirrors this
+        }
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            int n = nb0 + nt * 32 + 8 * g + 4 * lh;
+          for (int nh = 0; nh < 2; ++nh) {
+            int n = nb0 + nt * 32 + 16 * nh + 4 * e4;
             asm volatile("" : "+v"(n));
             const f32x4_t b4 = *reinterpret_cast<const f32x4_t*>(p.bias + n);
             const f32x4_t w4 = *reinterpret_cast<const f32x4_t*>(p.ln_w + n);
             const f32x4_t c4 = *reinterpret_cast<const f32x4_t*>(p.ln_b + n);
             const float bv[4] = {b4.x, b4.y, b4.z, b4.w}, wv[4] = {w4.x, w4.y, w4.z, w4.w}, cv[4] = {c4.x, c4.y, c4.z, c4.w};
-            float v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              v[q] = epi_gelu_erf_fast(fmaf(rn_mul((acc[nt][mt][4 * g + q] + bv[q]) - mean[mt], rstd[mt]), wv[q], cv[q]));
+            for (int mh = 0; mh < 2; ++mh) {
+              float v[4];
+#pragma unroll
+              for (int q = 0; q < 4; ++q)
+                v[q] = epi_gelu_erf_fast(fmaf(rn_mul((acc[nt][mt][2 * nh + mh][q] + bv[q]) - mu2[mh], rs2[mh]), wv[q], cv[q]));
+              block_put(h0, h1, nt, 2 * nh + ec, pack4(v[0], v[1], v[2], v[3]), mh * 16 + e16, eh);
             }
-            block_put(h0, h1, nt, g, pack4(v[0], v[1], v[2], v[3]), lr, lh);
           }
-        block_flush(h0, h1, m_blk, nb0, full_tag);
+        block_flush(h0, h1, m_blk, nb0, le, full_tag);
         __builtin_amdgcn_sched_barrier(0);
       }
+      __builtin_amdgcn_s_barrier();   // every wave has read its last partials: the slot may be refilled
+      asm volatile("" ::: "memory");
     } else if constexpr (STAGED32) {
       char* fs = smem + fslot * STAGE;
       const uint32_t h0 = lds_addr(fs + (wave * A_PW) * 1024);
       const uint32_t h1 = lds_addr(fs + A_BYTES + (wave * B_PW) * 1024);
-      const uint32_t wbase = ((lr >> 4) ? h1 : h0) + (lr & 15) * 256;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) {
         const int m_blk = m0 + wm * MT * 32 + mt * 32;
-        int b = ((FULL || m_blk + lr < p.M) ? m_blk + lr : p.M - 1) / p.L;
-        if (b > p.B - 1) b = p.B - 1;
+        f32x4_t bb[NT][2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt) {
-          f32x4_t bb[4];
-          lds_read4x16(bb, lds_addr(auxf + nb0 + nt * 32 + 4 * lh));
+        for (int nt = 0; nt < NT; ++nt) lds_read2x16(bb[nt], lds_addr(auxf + nb0 + nt * 32 + 4 * e4));
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            f32x4_t v = {acc[nt][mt][4 * g + 0] + bb[g].x, acc[nt][mt][4 * g + 1] + bb[g].y,
-                         acc[nt][mt][4 * g + 2] + bb[g].z, acc[nt][mt][4 * g + 3] + bb[g].w};
-            if constexpr (EPI == EPI_GATE_RES) {
-              const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 8 * g + 4 * lh);
-              v = f32x4_t{rn_mul(v.x, g4.x), rn_mul(v.y, g4.y), rn_mul(v.z, g4.z), rn_mul(v.w, g4.w)};
-            }
-            lds_write16(wbase + (((nt * 8 + 2 * g + lh) ^ (lr & 7)) << 4), v);
-          }
-        }
-        res_block(m_blk, nb0, h0, h1, full_tag);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    } else {
-      f32x4_t bb[NT][4];
-#pragma unroll
-      for (int nt = 0; nt < NT; ++nt) lds_read4x16(bb[nt], lds_addr(auxf + nb0 + nt * 32 + 4 * lh));
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        const int m_blk = m0 + wm * MT * 32 + mt * 32;
-        const int m = m_blk + lr;
-        const bool mok = FULL || m < p.M;
-        float4 gg[EPI == EPI_GATE_RES ? NT * 4 : 1];
-        if constexpr (EPI == EPI_GATE_RES) {
-          int b = m / p.L;
+        for (int mh = 0; mh < 2; ++mh) {
+          const int row = mh * 16 + e16;
+          const uint32_t wb = (mh ? h1 : h0) + e16 * 256;
+          int b = ((FULL || m_blk + row < p.M) ? m_blk + row : p.M - 1) / p.L;
           if (b > p.B - 1) b = p.B - 1;
 #pragma unroll
           for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int g = 0; g < 4; ++g)
-              gg[nt * 4 + g] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 8 * g + 4 * lh);
+            for (int nh = 0; nh < 2; ++nh) {
+              const f32x4_t a = acc[nt][mt][2 * nh + mh], b4 = bb[nt][nh];
+              f32x4_t v = {a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w};
+              if constexpr (EPI == EPI_GATE_RES) {
+                const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 16 * nh + 4 * e4);
+                v = f32x4_t{rn_mul(v.x, g4.x), rn_mul(v.y, g4.y), rn_mul(v.z, g4.z), rn_mul(v.w, g4.w)};
+              }
+              lds_write16(wb + (((nt * 8 + 4 * nh + e4) ^ (e16 & 7)) << 4), v);
+            }
         }
-        u32x2_t pk[NT][4];
+        res_block(m_blk, nb0, h0, h1, e4, e16, full_tag);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    } else {
+      f32x4_t bb[NT][2];
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+      for (int nt = 0; nt < NT; ++nt) lds_read2x16(bb[nt], lds_addr(auxf + nb0 + nt * 32 + 4 * e4));
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = nb0 + nt * 32 + 8 * g + 4 * lh;
-            const f32x4_t b4 = bb[nt][g];
-            float v[4] = {acc[nt][mt][4 * g + 0] + b4.x, acc[nt][mt][4 * g + 1] + b4.y,
-                          acc[nt][mt][4 * g + 2] + b4.z, acc[nt][mt][4 * g + 3] + b4.w};
-            if constexpr (EPI == EPI_BIAS_GELU) if (!ABL(64)) {   // diagnostic bit 64: no GELU arithmetic
-              const f32x2_t g0 = epi_gelu_tanh2(f32x2_t{v[0], v[1]}), g1 = epi_gelu_tanh2(f32x2_t{v[2], v[3]});
-              v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
-            }
-            if constexpr (EPI == EPI_BIAS_GELU_ERF) {
+      for (int mt = 0; mt < MT; ++mt) {
+        const int m_blk = m0 + wm * MT * 32 + mt * 32;
+        uint32_t h0 = 0, h1 = 0;
+        if constexpr (!RES) { h0 = blk_h0(fslot); h1 = blk_h1(fslot, h0); }
 #pragma unroll
-              for (int q = 0; q < 4; ++q) v[q] = epi_gelu_erf(v[q]);
-            }
-            if constexpr (RES) {
-              if constexpr (EPI == EPI_GATE_RES) {   // v already holds acc + bias (epi_gate_mul / epi_gate_res)
-                const float4 g4 = gg[nt * 4 + g];
-                v[0] = rn_mul(v[0], g4.x); v[1] = rn_mul(v[1], g4.y);
-                v[2] = rn_mul(v[2], g4.z); v[3] = rn_mul(v[3], g4.w);
-              }
-              if constexpr (PRE) {
-                if (mok) {
-                  const float4 r = res[(mt * NT + nt) * 4 + g];
-                  const float4 o = make_float4(rn_add(r.x, v[0]), rn_add(r.y, v[1]), rn_add(r.z, v[2]), rn_add(r.w, v[3]));
-                  *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = o;
-                }
-              }
-            } else {
-              pk[nt][g] = pack4(v[0], v[1], v[2], v[3]);
-            }
+        for (int mh = 0; mh < 2; ++mh) {
+          const int row = mh * 16 + e16;
+          const int m = m_blk + row;
+          const bool mok = FULL || m < p.M;
+          float4 gg[EPI == EPI_GATE_RES ? NT * 2 : 1];
+          if constexpr (EPI == EPI_GATE_RES) {
+            int b = m / p.L;
+            if (b > p.B - 1) b = p.B - 1;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+              for (int nh = 0; nh < 2; ++nh)
+                gg[nt * 2 + nh] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + nb0 + nt * 32 + 16 * nh + 4 * e4);
           }
-        if constexpr (!RES) store_block(pk, m_blk, nb0, fslot, full_tag);
+#pragma unroll
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+              const int n = nb0 + nt * 32 + 16 * nh + 4 * e4;
+              const f32x4_t a = acc[nt][mt][2 * nh + mh], b4 = bb[nt][nh];
+              float v[4] = {a.x + b4.x, a.y + b4.y, a.z + b4.z, a.w + b4.w};
+              if constexpr (EPI == EPI_BIAS_GELU) if (!ABL(64)) {   // diagnostic bit 64: no GELU arithmetic
+                const f32x2_t g0 = epi_gelu_tanh2(f32x2_t{v[0], v[1]}), g1 = epi_gelu_tanh2(f32x2_t{v[2], v[3]});
+                v[0] = g0.x; v[1] = g0.y; v[2] = g1.x; v[3] = g1.y;
+              }
+              if constexpr (EPI == EPI_BIAS_GELU_ERF) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) v[q] = epi_gelu_erf(v[q]);
+              }
+              if constexpr (RES) {
+                if constexpr (EPI == EPI_GATE_RES) {   // v already holds acc + bias (epi_gate_mul / epi_gate_res)
+                  const float4 g4 = gg[nt * 2 + nh];
+                  v[0] = rn_mul(v[0], g4.x); v[1] = rn_mul(v[1], g4.y);
+                  v[2] = rn_mul(v[2], g4.z); v[3] = rn_mul(v[3], g4.w);
+                }
+                if constexpr (PRE) {
+                  if (mok) {
+                    const float4 r = res[((mt * 2 + mh) * NT + nt) * 2 + nh];
+                    const float4 o = make_float4(rn_add(r.x, v[0]), rn_add(r.y, v[1]), rn_add(r.z, v[2]), rn_add(r.w, v[3]));
+                    *reinterpret_cast<float4*>(reinterpret_cast<float*>(p.C) + (size_t)m * p.ldc + n) = o;
+                  }
+                }
+              } else {
+                block_put(h0, h1, nt, 2 * nh + ec, pack4(v[0], v[1], v[2], v[3]), row, eh);
+              }
+            }
+        }
+        if constexpr (!RES) block_flush(h0, h1, m_blk, nb0, le, full_tag);
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -828,17 +884,19 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   auto load_residual = [&](int m0, int n0) {
     if constexpr (PRE) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) {
-        int m = m0 + wm * MT * 32 + mt * 32 + lr;
-        if (m > p.M - 1) m = p.M - 1;
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int nt = 0; nt < NT; ++nt)
+        for (int mh = 0; mh < 2; ++mh) {
+          int m = m0 + wm * MT * 32 + mt * 32 + mh * 16 + l16;
+          if (m > p.M - 1) m = p.M - 1;
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const int n = n0 + wn * NT * 32 + nt * 32 + 8 * g + 4 * lh;
-            res[(mt * NT + nt) * 4 + g] = *reinterpret_cast<const float4*>(p.xin + (size_t)m * p.ldc + n);
-          }
-      }
+          for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int nh = 0; nh < 2; ++nh) {
+              const int n = n0 + wn * NT * 32 + nt * 32 + 16 * nh + 4 * l4;
+              res[((mt * 2 + mh) * NT + nt) * 2 + nh] = *reinterpret_cast<const float4*>(p.xin + (size_t)m * p.ldc + n);
+            }
+        }
     }
   };
 
@@ -910,7 +968,7 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
 #pragma unroll
       for (int b = 0; b < MT; ++b)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+        for (int r = 0; r < 4; ++r) acc[a][b][r] = f32x4_t{0.f, 0.f, 0.f, 0.f};
    STAMP(5);
    auto step = [&](int kt, auto last_tag) {
     constexpr bool LAST = decltype(last_tag)::value;   // the tile's last k-step (peeled out of the loop)
@@ -928,15 +986,17 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     const char* base = smem + slot * STAGE;
 #pragma unroll
     for (int ph = 0; ph < PH; ++ph) {
-      bf16x8 xf[KP][MT], wf[KP][NT];
+      bf16x8 xf[MT][2], wf[NT][2];   // [32-row block][16-row half]
+      {
+        const int cxk = cx[ph];
 #pragma unroll
-      for (int k2 = 0; k2 < KP; ++k2) {
-        const int kk = ph * KP + k2;
-        const int cxk = cx[kk];
+        for (int t = 0; t < NT; ++t)
 #pragma unroll
-        for (int t = 0; t < NT; ++t) wf[k2][t] = *reinterpret_cast<const bf16x8*>(base + b_lane + cxk + t * 32 * ROWB);
+          for (int h = 0; h < 2; ++h) wf[t][h] = *reinterpret_cast<const bf16x8*>(base + b_lane + cxk + (t * 32 + h * 16) * ROWB);
 #pragma unroll
-        for (int t = 0; t < MT; ++t) xf[k2][t] = *reinterpret_cast<const bf16x8*>(base + a_lane + cxk + t * 32 * ROWB);
+        for (int t = 0; t < MT; ++t)
+#pragma unroll
+          for (int h = 0; h < 2; ++h) xf[t][h] = *reinterpret_cast<const bf16x8*>(base + a_lane + cxk + (t * 32 + h * 16) * ROWB);
       }
       if (ph == PH - 1 && s + 1 < total) {
         int ahead = total - 2 - s;
@@ -954,38 +1014,21 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
       if (!ABL(8)) __builtin_amdgcn_s_barrier();
       STAMP(3);
       __builtin_amdgcn_sched_barrier(0);
+      if (ABL(2)) {
 #pragma unroll
-      for (int k2 = 0; k2 < KP; ++k2) {
-        if (ABL(2)) {
+        for (int t = 0; t < NT; ++t) { asm volatile("" ::"v"(wf[t][0])); asm volatile("" ::"v"(wf[t][1])); }
 #pragma unroll
-          for (int t = 0; t < NT; ++t) asm volatile("" ::"v"(wf[k2][t]));
+        for (int t = 0; t < MT; ++t) { asm volatile("" ::"v"(xf[t][0])); asm volatile("" ::"v"(xf[t][1])); }
+      } else {
 #pragma unroll
-          for (int t = 0; t < MT; ++t) asm volatile("" ::"v"(xf[k2][t]));
-        } else {
-#if defined(SGPO_GEMM_ABLATE) && defined(SGPO_MFMA16)
-          // Diagnostic build only (round 3): the same flops as 16x16x32 MFMAs on the same fragments -- WRONG results, K loop
-          // timing only (run with the epilogue ablated).  MI355X_MICROARCH.md, DVFS item 7: the 16x16x32 shape holds a
-          // higher clock under load.  Two k-slices of a phase give four 16x16x32 products per 32x32 accumulator.
-          if (k2 == 0) {
+        for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-              for (int mt = 0; mt < MT; ++mt) {
-                f32x4_t* a4 = reinterpret_cast<f32x4_t*>(&acc[nt][mt]);
-                a4[0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[0][mt], a4[0], 0, 0, 0);
-                a4[1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[0][nt], xf[KP - 1][mt], a4[1], 0, 0, 0);
-                a4[2] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[KP - 1][nt], xf[0][mt], a4[2], 0, 0, 0);
-                a4[3] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[KP - 1][nt], xf[KP - 1][mt], a4[3], 0, 0, 0);
-              }
-          }
-#else
+            for (int nh = 0; nh < 2; ++nh)
 #pragma unroll
-          for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-            for (int mt = 0; mt < MT; ++mt)
-              acc[nt][mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[k2][nt], xf[k2][mt], acc[nt][mt], 0, 0, 0);
-#endif
-        }
+              for (int mh = 0; mh < 2; ++mh)
+                acc[nt][mt][2 * nh + mh] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][nh], xf[mt][mh], acc[nt][mt][2 * nh + mh], 0, 0, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
       STAMP(4);
