@@ -1090,6 +1090,8 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   constexpr int BM = CFG::WM * CFG::MT * 32, BN = CFG::WN * CFG::NT * 32;
   constexpr int RING = CFG::NST * (BM + BN) * CFG::BK * 2;
   constexpr bool F32OUT = (EPI == EPI_BIAS_F32 || EPI == EPI_ACC_F32);
+  // segmented (dilated-convolution) operands exist for the epilogues ByteNet ends a convolution with
+  constexpr bool CONV_OK = (EPI == EPI_BF16 || EPI == EPI_BIAS_F32 || EPI == EPI_LN_GELU);
   if (q.K % CFG::BK != 0 || sg.seg_k % CFG::BK != 0) return SGPO_ERR_UNSUPPORTED;
   int flags = PF_EXACT;
   size_t aux = 0;
@@ -1110,13 +1112,13 @@ static int launch_cfg(const GemmParams& q, const GemmSeg& sg, const bf16_t* zero
   if (!attr_set) {
     SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, false, CFG, ROPE_LDS>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
-    if constexpr (EPI != EPI_GATE_RES_LN)   // (no convolution ends in a gated residual)
+    if constexpr (CONV_OK)
       SGPO_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_p_kernel<EPI, true, CFG, ROPE_LDS>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, LDS_MAX_BYTES));
     attr_set = true;
   }
   if (sg.n_seg > 1) {
-    if constexpr (EPI == EPI_GATE_RES_LN) return SGPO_ERR_UNSUPPORTED;
+    if constexpr (!CONV_OK) return SGPO_ERR_UNSUPPORTED;   // the caller falls back to the generic kernel (gemm.hip)
     else hipLaunchKernelGGL((gemm_p_kernel<EPI, true, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
   } else
     hipLaunchKernelGGL((gemm_p_kernel<EPI, false, CFG, ROPE_LDS>), dim3(grid), dim3(512), lds, stream, q, sg, zero16, ntm, ntn, grouped, flags, dbg);
