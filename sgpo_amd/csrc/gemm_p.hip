@@ -59,6 +59,9 @@ template <typename C> struct is_row_cfg : std::is_same<C, CfgRow> {};
 #endif
 
 enum { PF_EXACT = 1 };
+#ifndef SGPO_G1_PRIO
+#define SGPO_G1_PRIO 1
+#endif
 #define LDS_MAX_BYTES 163840
 
 #ifdef SGPO_GEMM_ABLATE   // diagnostic build only (tools/dbg): skip parts of the kernel at run time
@@ -987,6 +990,11 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
     asm volatile("" ::: "memory");
   }
   if (grp == 1 && !ABL(8)) __builtin_amdgcn_s_barrier();
+  // Waves 4-7 are the younger half of the workgroup and lose every arbitration (issue, LDS, address queue) to their SIMD
+  // partners: their fragment reads and DMA issue took 1.9x / 1.25x the cycles of waves 0-3 (cycle stamps), and the older
+  // half waited for them at the phase barriers.  One static priority raise for that half (cdna_hip_programming.md T5,
+  // static form): fc1+GELU 1180 -> 1134 us, QKV 848 -> 833.  Not on the full-row tile, where it measured +0.6 %.
+  if (grp == 1 && !ROW) __builtin_amdgcn_s_setprio(SGPO_G1_PRIO);
   STAMP_DECL
   int slot = 0;   // ring slot of step s
   int s = 0;      // position in the flattened (tile, k-step) stream
