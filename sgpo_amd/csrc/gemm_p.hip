@@ -13,9 +13,11 @@
 //     steps that follow the wait count includes them (exact count: the epilogue of a full tile
 //     issues a compile-time number of store instructions and no loads -- bias and the RoPE table
 //     are copied to LDS once per launch);
-//   * the MFMA is issued "swapped" (A operand = weight rows, B operand = activation rows) so a lane
-//     owns ONE output row and 4 consecutive columns per register quad: epilogues store 8 B (bf16)
-//     or 16 B (fp32) per lane instead of 2-4 B, and RoPE pairs (d, d+32) stay lane-local;
+//   * the MFMA (v_mfma_f32_16x16x32_bf16 since round 3: the chip holds a higher clock on it than on
+//     32x32x16 at equal cycles per flop) is issued "swapped" (A operand = weight rows, B operand =
+//     activation rows) so a register quad is 4 consecutive columns of ONE output row: a lane owns two
+//     rows and two column quads of every 32x32 block, epilogues move 8 B (bf16) or 16 B (fp32) per
+//     lane and quad instead of 2-4 B, and RoPE pairs (d, d+32) stay lane-local;
 //   * tiles are dealt so that the N-tiles of one A row panel run on workgroups of one XCD
 //     (`blockIdx % 8` labels the XCD group): the panel is fetched from HBM once per XCD L2.
 // Two tile configurations (the staging traffic per flop, not the MFMA rate, bounds these shapes:

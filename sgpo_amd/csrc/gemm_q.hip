@@ -7,7 +7,9 @@
 // of the 256 x 256 tile, and BK = 32 (64-byte rows in the LDS image) so that a 3-slot ring fits 80 KiB per workgroup.
 //
 //   C[M,N] = A[M,K] * W[N,K]^T (+ epilogue), A / W bf16 row-major with K contiguous, fp32 accumulate,
-//   v_mfma_f32_32x32x16_bf16 in the same k order as gemm.hip / gemm_p.hip (same accumulator bits).
+//   v_mfma_f32_32x32x16_bf16 in the k order of gemm.hip / gemm_p.hip.  (It gave the accumulator bits of those two kernels when it
+//   was measured; they have since moved to the 16x16x32 shape, this experiment has not: it agrees with them to fp32
+//   summation order only.  Not on any product path.)
 //
 // Stream per workgroup: (tile, k-step) flattened; at step s the wave issues the LDS-DMA of step s + 2 into the slot of
 // step s - 1, reads its fragments of step s, waits for its own DMA pieces of step s + 1 (counted vmcnt) and for its

@@ -21,7 +21,8 @@ def timed(fn):
     return e0.elapsed_time(e1) / reps * 1e3
 
 
-# correctness first, on a ragged shape: bias-only epilogue must equal bf16(acc + bias) of the reference GEMM bit for bit
+# correctness first, on a ragged shape: the bias-only epilogue against bf16(acc + bias) of the product GEMM (bit for bit while both
+# used the 32x32x16 MFMA shape; the product kernels moved to 16x16x32 in round 3, so a few last-bit differences are expected now)
 for (m, n, k) in ((1000, 256, 512), (777, 1536, 512), (4097, 2048, 512)):
     a = (torch.randn(m, k, generator=g) * 0.5).to(torch.bfloat16).cuda()
     w = (torch.randn(n, k, generator=g) * 0.05).to(torch.bfloat16).cuda()
