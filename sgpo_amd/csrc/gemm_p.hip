@@ -995,8 +995,9 @@ __global__ __launch_bounds__(512) void gemm_p_kernel(GemmParams p, GemmSeg sg, c
   // Waves 4-7 are the younger half of the workgroup and lose every arbitration (issue, LDS, address queue) to their SIMD
   // partners: their fragment reads and DMA issue took 1.9x / 1.25x the cycles of waves 0-3 (cycle stamps), and the older
   // half waited for them at the phase barriers.  One static priority raise for that half (cdna_hip_programming.md T5,
-  // static form): fc1+GELU 1180 -> 1134 us, QKV 848 -> 833.  Not on the full-row tile, where it measured +0.6 %.
-  if (grp == 1 && !ROW) __builtin_amdgcn_s_setprio(SGPO_G1_PRIO);
+  // static form): fc1+GELU 1180 -> 1134 us, QKV 848 -> 833.  Only for the bf16-output epilogues: on the full-row tile it measured
+  // +0.6 %, on the staged fp32 residual epilogue (ByteNet's residual GEMM) +1.3 %.
+  if (grp == 1 && !ROW && !RES && !F32OUT) __builtin_amdgcn_s_setprio(SGPO_G1_PRIO);
   STAMP_DECL
   int slot = 0;   // ring slot of step s
   int s = 0;      // position in the flattened (tile, k-step) stream
